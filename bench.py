@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the ViT-B/16 224x224 fp32 forward at batch 256 per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = one forward of one batch of synthetic images already resident in HBM, through the C-ABI
+(vit_engine_forward_device) on this rank's GPU; with N > 1 every rank owns its own batch (weak
+scaling, no data-path collective) and the per-image top-1 records are all-gathered over RCCL at
+the end of each step (the only exchange the north star asks for).  One JSON line on rank 0.
+
+Extra objects in the line:
+  roofline      the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs per launch / average launch
+                duration from HIP events recorded on the launch stream during the timed steps.
+  cpu_baseline  the CPU oracle (bit-identical restatement of the reference's ViT_seq.c) timed on one
+                host core on one image of the same batch; the GPU row for that image is checked
+                against it (1e-4 on probabilities, same top-1).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "images/sec ViT-B/16 224² fp32 @batch256; % MFMA roofline; top-1 match"
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it
+    "qkv": "gemm_f32_nt_kernel<EPI_BIAS>", "head": "gemm_f32_nt_kernel<EPI_BIAS>",
+    "fc1": "gemm_f32_nt_kernel<EPI_BIAS_GELU>",
+    "outproj": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>",
+    "attn": "attention_f32_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
+    "softmax": "softmax_top1_f32_kernel",
+}
+
+
+def stage_macs(cfg, batch):
+    T, D, H = cfg.tokens, cfg.embed_dim, cfg.hidden_dim
+    M = batch * T
+    hd = D // cfg.num_heads
+    return {  # algorithmic MACs of ONE launch of each stage (SURVEY.md 8d breakdown x batch)
+        "embed": batch * cfg.patches * cfg.patch_dim * D,
+        "qkv": M * D * 3 * D, "attn": batch * 2 * cfg.num_heads * T * T * hd, "outproj": M * D * D,
+        "fc1": M * D * H, "fc2": M * D * H, "head": batch * D * cfg.num_classes, "ln": 0, "softmax": 0,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (metric config: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    pkg = importlib.import_module("vision-transformer-opencl_amd")
+    binding = importlib.import_module("vision-transformer-opencl_amd.binding")
+    synth = pkg.synth
+    cfg = pkg.VIT_B16
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    binding.lib().vithip_gemm_set_tile(args.gemm_tile)
+    weights = synth.make_weights(cfg, 1234)
+    eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=True)
+    eng.load_weights(weights)
+
+    # synthetic batch, generated on the host with the repo PRNG for the first images (so that the
+    # CPU baseline sees the same bytes) and tiled on the device; resident in HBM before timing.
+    n_distinct = min(B, 8)
+    host_imgs = synth.make_images(cfg, n_distinct, seed=99 + 1000 * rank)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        base = torch.from_numpy(host_imgs).to(dev)
+        reps = (B + n_distinct - 1) // n_distinct
+        images = base.repeat(reps, 1, 1, 1)[:B].contiguous()
+        # decorrelate the copies a little so the batch is not B/8 identical groups
+        off = torch.arange(B, device=dev, dtype=torch.float32)
+        off[:n_distinct] = 0.0
+        images += 1e-3 * off.view(B, 1, 1, 1)
+        probs = torch.empty((B, cfg.num_classes), device=dev, dtype=torch.float32)
+        top1 = torch.empty((2, B), device=dev, dtype=torch.int32)  # row 0 labels, row 1 prob bits
+        gathered = torch.empty((world, 2, B), device=dev, dtype=torch.int32) if world > 1 else None
+    stream.synchronize()
+    sptr = stream.cuda_stream
+
+    def step():
+        eng.forward_device(images.data_ptr(), B, probs.data_ptr(), top1[0].data_ptr(), top1[1].data_ptr(), sptr)
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.all_gather_into_tensor(gathered.view(-1), top1.view(-1))
+
+    def fence():
+        stream.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.reset_stage_times()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    times = eng.stage_times()
+
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+    gflop_img = 2.0 * cfg.macs_per_image / 1e9
+    model_tflops = value * gflop_img / 1e3 / world  # per GPU
+
+    # ---- roofline of the dominant kernel (per-launch, from the stage brackets) -------------------
+    macs = stage_macs(cfg, B)
+    per_kernel = {}
+    for stage, rec in times["stages"].items():
+        k = STAGE_KERNEL[stage]
+        d = per_kernel.setdefault(k, {"ms": 0.0, "launches": 0, "flop": 0.0})
+        d["ms"] += rec["ms"]
+        d["launches"] += rec["launches"]
+        d["flop"] += 2.0 * macs[stage] * rec["launches"]
+    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = dom["ms"] / max(dom["launches"], 1)
+    achieved = dom["flop"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    gemm_ms = sum(v["ms"] for k, v in per_kernel.items() if k.startswith("gemm"))
+    gemm_flop = sum(v["flop"] for k, v in per_kernel.items() if k.startswith("gemm"))
+    roofline = {
+        "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+        "flop_per_launch": dom["flop"] / max(dom["launches"], 1),
+        "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
+        "whole_model_tflops": round(model_tflops, 2),
+        "whole_model_frac": round(model_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+        "stage_ms_per_step": {s: round(r["ms"] / args.steps, 3) for s, r in times["stages"].items()},
+    }
+
+    # ---- CPU baseline + parity on the sampled image (rank 0, N = 1 only) -------------------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        ocfg = po.Config(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.num_classes, cfg.embed_dim,
+                         cfg.depth, cfg.num_heads, cfg.hidden_dim)
+        po.set_threads(args.cpu_threads)
+        t1 = time.perf_counter()
+        ref_p, _, _ = po.forward_image(ocfg, host_imgs[0], weights)
+        cpu_dt = time.perf_counter() - t1
+        got = probs[0].cpu().numpy()
+        err = float(np.abs(got - ref_p).max())
+        parity = {"max_abs_prob_err": err, "top1_match": bool(int(got.argmax()) == int(ref_p.argmax())),
+                  "tolerance": 1e-4}
+        cpu = {"value": round(1.0 / cpu_dt, 5), "unit": "images/sec", "cores": args.cpu_threads, "kind": "port",
+               "sample": f"image 0 of the batch (1 of {B}), {cpu_dt:.2f} s, oracle/vit_cpu_ref.c gcc -O2 -ffp-contract=off"}
+
+    if rank == 0:
+        info = binding.device_info(local_rank)
+        print(json.dumps({
+            "metric": METRIC, "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ViT-B/16 224x224 fp32 forward, batch 256 per GPU, synthetic weights and images (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "gflop_per_image": round(gflop_img, 4), "device": info["name"], "arch": info["arch"],
+                       "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        }))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+/*
+ * include/vit_engine.h -- the batched ViT forward engine (host side, plain C).
+ *
+ * This is the re-entrant object underneath the reference-shaped facade of ViT_hip.h.  It owns
+ * what the reference's OpenCL path re-creates on every call (ViT_opencl.c:126-883: buffers,
+ * weight uploads, per-op blocking reads): device-resident weights uploaded ONCE, a workspace
+ * sized for a whole batch, one in-order HIP stream, and the layer loop that enqueues the
+ * kernels of vit_hip_kernels.h.  The forward is ViT_seq.c:337-439 for a batch of images
+ * (the reference loops `for i < image->n`, ViT_seq.c:354; here the batch is the GEMM M dimension).
+ *
+ * All functions return VIT_OK or an error code; vit_engine_last_error() gives the message.
+ * Nothing here prints or exits -- that convention belongs to the facade (ViT_hip.h).
+ */
+#ifndef VIT_ENGINE_H
+#define VIT_ENGINE_H
+
+#include "vit_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    VIT_OK = 0,
+    VIT_ERR_ARG = 1,      /* bad argument / unsupported configuration */
+    VIT_ERR_WEIGHTS = 2,  /* missing or mis-sized weight tensor */
+    VIT_ERR_HIP = 3,      /* a HIP call failed (message carries the hipError string) */
+    VIT_ERR_NOMEM = 4,
+    VIT_ERR_STATE = 5     /* e.g. forward before weights were loaded */
+};
+
+typedef struct vit_engine vit_engine;
+
+typedef struct {
+    int device;      /* HIP device ordinal */
+    int max_batch;   /* images per forward chunk (workspace is sized for it); default 256 */
+    int profile;     /* 1: bracket every stage with events and accumulate vit_stage_times */
+} vit_engine_options;
+
+/* Per-stage device time of the profiled forwards (ms, summed) and launch counts. */
+enum {
+    VIT_STAGE_EMBED = 0, VIT_STAGE_LN, VIT_STAGE_QKV, VIT_STAGE_ATTN, VIT_STAGE_OUTPROJ,
+    VIT_STAGE_FC1, VIT_STAGE_FC2, VIT_STAGE_HEAD, VIT_STAGE_SOFTMAX, VIT_STAGE_COUNT
+};
+typedef struct {
+    double ms[VIT_STAGE_COUNT];
+    long launches[VIT_STAGE_COUNT];
+    long images;  /* images covered by the profiled forwards */
+} vit_stage_times;
+
+/* ViT-B/16-224: the reference's macros (ViT_seq.c:10-21). */
+vit_config vit_config_b16(void);
+/* tokens = (img/patch)^2 + 1 */
+int vit_config_tokens(const vit_config *cfg);
+/* Expected element count of weight tensor `index` (reference index map); 0 if out of range. */
+size_t vit_config_weight_size(const vit_config *cfg, int index);
+/* Algorithmic MACs of one image (17,563,828,224 for ViT-B/16-224). */
+unsigned long long vit_config_macs_per_image(const vit_config *cfg);
+
+void vit_engine_default_options(vit_engine_options *opt);
+int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_options *opt);
+void vit_engine_destroy(vit_engine *e);
+const char *vit_engine_last_error(const vit_engine *e);
+const vit_config *vit_engine_config(const vit_engine *e);
+
+/*
+ * Validate (non-NULL, exact element count -- the reference's loader validates nothing,
+ * Network.c:147) and upload all `count` = VIT_WEIGHT_COUNT(depth) tensors once.
+ * The host arrays are only borrowed during the call.
+ */
+int vit_engine_load_weights(vit_engine *e, const Network *weights, int count);
+
+/*
+ * Device-resident forward: d_images [n][C][S][S] fp32 -> d_probs [n][classes] fp32, both in
+ * HBM, n arbitrary (processed in chunks of max_batch).  Asynchronous on `stream`
+ * (a hipStream_t; NULL = the engine's own stream, then call vit_engine_sync()).
+ * d_top1_label / d_top1_prob (device, n entries each) may be NULL.
+ */
+int vit_engine_forward_device(vit_engine *e, const float *d_images, int n, float *d_probs,
+                              int *d_top1_label, float *d_top1_prob, void *stream);
+int vit_engine_sync(vit_engine *e);
+
+/*
+ * Host-pointer forward with the reference's ownership rules (ViT_opencl.h:18): images[i] are
+ * separately allocated CHW buffers, probs[i] caller-allocated [classes] rows.  Stages through
+ * pinned buffers; blocking.
+ */
+int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, float *const *probs);
+
+/* Debug/test taps: copy the logits of the most recent chunk (rows = images of that chunk). */
+int vit_engine_read_logits(vit_engine *e, float *dst, int rows);
+
+int vit_engine_get_stage_times(vit_engine *e, vit_stage_times *out);  /* syncs, then reports */
+void vit_engine_reset_stage_times(vit_engine *e);
+int vit_engine_set_profile(vit_engine *e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_ENGINE_H */

@@ -1,0 +1,141 @@
+/*
+ * include/vit_hip_kernels.h -- the thin C-ABI over HIP.
+ *
+ * The host side of this project is C (as the reference's is); everything that needs the HIP
+ * runtime or a gfx950 kernel sits behind these extern "C" entry points, compiled by hipcc
+ * (csrc/ *.hip).  Only plain pointers, sizes and ints cross the boundary.  Each launcher is
+ * asynchronous on the given stream (NULL = the default stream) and returns 0 on success or
+ * a hipError_t value; vithip_error_string() renders it.
+ *
+ * What each kernel launcher replaces in the reference's OpenCL path:
+ *   vithip_patch_embed_f32   Conv2d_opencl + CPU flatten_transpose/class_token/pos_emb
+ *                            (ViT_opencl.c:126-180,806-810; kernel.cl:120-175)
+ *   vithip_layernorm_f32     layer_norm_opencl (ViT_opencl.c:233-291; kernel.cl:6-80) -- but with
+ *                            ViT_seq.c:103-121 numerics (eps = 1e-6, added in double)
+ *   vithip_gemm_f32          enqueue_gemm_stage/add_bias_helper, fc1/gelu/fc2 kernels,
+ *                            linear_layer_opencl and the CPU residual adds
+ *                            (ViT_opencl.c:294-335,369-380,449-497,607-729,758-777;
+ *                             kernel.cl:208-284,374-533) with exact-erf GELU (ViT_seq.c:231-233)
+ *   vithip_attention_f32     the per-head scores GEMM / softmax / P.V chain
+ *                            (ViT_opencl.c:499-602; kernel.cl:289-365), ViT_seq.c:156-215 numerics
+ *   vithip_softmax_top1_f32  CPU Softmax (ViT_opencl.c:881 -> ViT_seq.c:304-324) and the
+ *                            argmax loop of Main.c:62-72
+ */
+#ifndef VIT_HIP_KERNELS_H
+#define VIT_HIP_KERNELS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *vithip_stream_t; /* hipStream_t     */
+typedef void *vithip_event_t;  /* hipEvent_t      */
+typedef void *vithip_graph_t;  /* hipGraphExec_t  */
+
+typedef struct {
+    char name[256];
+    char arch[64];            /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    int compute_units;
+    int clock_mhz;            /* max engine clock */
+    int wavefront;
+    int lds_per_block;        /* bytes */
+    unsigned long long hbm_bytes;
+} vithip_device_info;
+
+/* ---- runtime plumbing --------------------------------------------------------------- */
+const char *vithip_error_string(int code);
+int vithip_device_count(int *count);
+int vithip_set_device(int device);
+int vithip_get_device_info(int device, vithip_device_info *info);
+int vithip_malloc(void **ptr, size_t bytes);
+int vithip_free(void *ptr);
+int vithip_host_alloc(void **ptr, size_t bytes);   /* pinned */
+int vithip_host_free(void *ptr);
+int vithip_memcpy_h2d(void *dst, const void *src, size_t bytes, vithip_stream_t stream);
+int vithip_memcpy_d2h(void *dst, const void *src, size_t bytes, vithip_stream_t stream);
+int vithip_memcpy_d2d(void *dst, const void *src, size_t bytes, vithip_stream_t stream);
+int vithip_memset(void *dst, int value, size_t bytes, vithip_stream_t stream);
+int vithip_stream_create(vithip_stream_t *stream);
+int vithip_stream_destroy(vithip_stream_t stream);
+int vithip_stream_sync(vithip_stream_t stream);
+int vithip_device_sync(void);
+int vithip_event_create(vithip_event_t *event);
+int vithip_event_destroy(vithip_event_t event);
+int vithip_event_record(vithip_event_t event, vithip_stream_t stream);
+int vithip_event_sync(vithip_event_t event);
+int vithip_event_elapsed_ms(float *ms, vithip_event_t start, vithip_event_t stop);
+int vithip_stream_wait_event(vithip_stream_t stream, vithip_event_t event);
+int vithip_graph_begin(vithip_stream_t stream);
+int vithip_graph_end(vithip_stream_t stream, vithip_graph_t *graph);
+int vithip_graph_launch(vithip_graph_t graph, vithip_stream_t stream);
+int vithip_graph_destroy(vithip_graph_t graph);
+
+/* ---- kernels ------------------------------------------------------------------------- */
+
+enum { VITHIP_EPI_BIAS = 0, VITHIP_EPI_BIAS_GELU = 1, VITHIP_EPI_BIAS_RESIDUAL = 2 };
+
+/*
+ * C[M][ldc] (first N columns) = epilogue(A[M][K] . W[N][K]^T + bias[N]):
+ * the shape of every linear layer of the model (weights are [out][in], K contiguous in both
+ * operands).  fp32 in, fp32 MFMA accumulate (v_mfma_f32_32x32x2_f32), fp32 out.
+ *   EPI_BIAS_GELU:     y = 0.5*y*(1+erff(y/sqrtf(2)))                 (ViT_seq.c:231-233)
+ *   EPI_BIAS_RESIDUAL: y += residual[m][n]; residual may alias C      (ViT_seq.c:286-288,297-299)
+ * Requirements: K % 32 == 0; lda, ldw, ldc, ldr % 4 == 0; W must provide ceil(N/32)*32 rows
+ * (pad rows are read, never used); all pointers 16-byte aligned.
+ */
+typedef struct {
+    const float *A; int lda;
+    const float *W; int ldw;
+    const float *bias;
+    const float *residual; int ldr;
+    float *C; int ldc;
+    int M, N, K;
+    int epilogue;
+} vithip_gemm_args;
+int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
+/* Tuning hook for benchmarks: workgroup tile 0/1 = 128x128 (default), 2 = 256x128, 3 = 128x64. */
+int vithip_gemm_set_tile(int tile);
+
+/*
+ * Patch embedding straight from NCHW images (implicit GEMM over the 16x16 patches), with the
+ * embedding tail fused into the store:
+ *   x[img][0][:]     = cls[:] + pos[0][:]
+ *   x[img][1+p][:]   = conv_bias[:] + sum_{ic,kh,kw} image * conv_w + pos[1+p][:]
+ * images: [n][C][S][S]; conv_w: [D][C*P*P]; x: [n][T][D], T = (S/P)^2 + 1.
+ */
+int vithip_patch_embed_f32(vithip_stream_t stream, const float *images, const float *conv_w,
+                           const float *conv_b, const float *cls, const float *pos, float *x,
+                           int n_images, int img_size, int patch_size, int in_chans, int embed_dim);
+
+/*
+ * y[r][0..dim) = (x[r] - mean) * inv_std * gamma + beta for rows r = 0..rows-1 where row r
+ * starts at x + r*ldx (ldx lets the final LayerNorm touch only the class-token rows).
+ * mean/var as ViT_seq.c:103-121: var = E[x^2] - mean^2, inv_std = 1/sqrtf((double)var + 1e-6).
+ * dim % 4 == 0, dim <= 2048.
+ */
+int vithip_layernorm_f32(vithip_stream_t stream, const float *x, size_t ldx, float *y, size_t ldy,
+                         const float *gamma, const float *beta, int rows, int dim);
+
+/*
+ * Fused scaled-dot-product attention, one workgroup per (image, head).
+ * qkv: [n*T][3*D] rows = tokens, columns [Q | K | V], head h = columns 64h..64h+63 of each.
+ * out: [n*T][D].  scores = q.k / sqrtf(64); row softmax with max subtraction; out = P.V.
+ * head_dim must be 64; tokens <= 224 (K and V of one head stay resident in LDS).
+ */
+int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
+                         int n_images, int tokens, int heads);
+
+/*
+ * probs[r][0..classes) = softmax(logits[r]) (ViT_seq.c:304-324) and the top-1 record
+ * (first index of the maximum probability, Main.c:62-70).  top1_label / top1_prob may be NULL.
+ */
+int vithip_softmax_top1_f32(vithip_stream_t stream, const float *logits, int ld_logits,
+                            float *probs, int ld_probs, int *top1_label, float *top1_prob,
+                            int rows, int classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_HIP_KERNELS_H */

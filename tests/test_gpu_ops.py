@@ -1,0 +1,164 @@
+"""Op-level parity: every HIP kernel, called through the C-ABI, against the CPU oracle.
+
+The oracle (oracle/vit_cpu_ref.c) is bit-identical to the reference's ViT_seq.c; the kernels sum
+in a different order (MFMA k-blocking, wave reductions), so the bar is the north star's fp32
+tolerance: 1e-4 absolute on softmax outputs, and a relative 2e-5 of the tensor's magnitude on
+unnormalised activations (the measured oracle noise is ~6e-6).
+"""
+import numpy as np
+import pytest
+
+from vit_amd import binding as B
+from vit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5
+
+
+def u(k, shape, a, seed=777):
+    n = int(np.prod(shape))
+    return synth.uniform(seed, k, n, -a, a).reshape(shape)
+
+
+def close(a, b, rel=REL):
+    scale = float(np.abs(b).max()) + 1e-30
+    err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+    assert err <= rel * scale, f"max err {err:.3e} > {rel} * {scale:.3e}"
+
+
+# ---- GEMM ---------------------------------------------------------------------------------------
+
+def test_gemm_identity_asymmetric_exact():
+    """A = I with an asymmetric W: C must be W^T exactly (catches any fragment/row/col swap)."""
+    K = 256
+    A = np.eye(K, dtype=np.float32)
+    W = u(1, (160, K), 1.0)
+    bias = np.zeros(160, np.float32)
+    C = B.gemm(A, W, bias)
+    assert np.array_equal(C, W.T.copy())
+
+
+@pytest.mark.parametrize("M,N,K", [(197, 768, 768), (394, 2304, 768), (300, 1000, 768), (5, 10, 128),
+                                   (129, 33, 64), (1, 1000, 768), (640, 256, 3072)])
+def test_gemm_bias(oracle, M, N, K):
+    A, W, b = u(2, (M, K), 1.0), u(3, (N, K), 0.05), u(4, (N,), 0.1)
+    close(B.gemm(A, W, b), oracle.linear(A, W, b))
+
+
+def test_gemm_bias_gelu(oracle):
+    M, N, K = 394, 3072, 768
+    A, W, b = u(5, (M, K), 1.0), u(6, (N, K), 0.08), u(7, (N,), 0.1)
+    ref = oracle.linear(A, W, b)
+    ref = oracle.gelu(ref)
+    got = B.gemm(A, W, b, epilogue=B.EPI_BIAS_GELU)
+    close(got, ref)
+
+
+def test_gemm_bias_residual(oracle):
+    M, N, K = 394, 768, 3072
+    A, W, b, R = u(8, (M, K), 1.0), u(9, (N, K), 0.03), u(10, (N,), 0.1), u(11, (M, N), 2.0)
+    ref = R + oracle.linear(A, W, b)  # ViT_seq.c:297-299: residual + mlp_out
+    close(B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL), ref)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_tile_variants(oracle, tile):
+    M, N, K = 515, 200, 96
+    A, W, b = u(12, (M, K), 1.0), u(13, (N, K), 0.1), u(14, (N,), 0.1)
+    B.lib().vithip_gemm_set_tile(tile)
+    try:
+        close(B.gemm(A, W, b), oracle.linear(A, W, b))
+    finally:
+        B.lib().vithip_gemm_set_tile(0)
+
+
+def test_gemm_rejects_bad_k():
+    A, W, b = u(15, (8, 40), 1.0), u(16, (8, 40), 1.0), u(17, (8,), 1.0)
+    with pytest.raises(B.VitError):
+        B.gemm(A, W, b)  # K = 40 is not a multiple of 32
+
+
+# ---- LayerNorm ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("rows,dim", [(197, 768), (50, 128), (7, 1024), (3, 192), (1000, 768)])
+def test_layernorm(oracle, rows, dim):
+    x = u(20, (rows, dim), 3.0) + 0.5
+    g, b = synth.uniform(777, 21, dim, 0.5, 1.5), u(22, (dim,), 0.5)
+    close(B.layernorm(x, g, b), oracle.layer_norm(x, g, b))
+
+
+def test_layernorm_constant_row_uses_eps(oracle):
+    """var == 0: the result is decided by the 1e-6 epsilon the OpenCL kernel forgot."""
+    x = np.full((4, 768), 1.25, np.float32)
+    g, b = np.ones(768, np.float32), np.zeros(768, np.float32)
+    got = B.layernorm(x, g, b)
+    assert np.isfinite(got).all()
+    close(got, oracle.layer_norm(x, g, b), rel=1e-3)
+
+
+# ---- attention ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (3, 5, 2), (2, 50, 3), (1, 33, 1), (1, 224, 2), (1, 32, 1),
+                                       (2, 129, 2)])
+def test_attention(oracle, n, T, heads):
+    D = heads * 64
+    qkv = u(30, (n * T, 3 * D), 1.5)
+    got = B.attention(qkv, n, T, heads).reshape(n, T, D)
+    for i in range(n):
+        blk = qkv[i * T:(i + 1) * T]
+        q, k, v = (np.ascontiguousarray(blk[:, j * D:(j + 1) * D]) for j in range(3))
+        ref = oracle.attention_core(q, k, v, heads)
+        err = float(np.abs(got[i] - ref).max())
+        assert err <= 1e-5 * max(1.0, float(np.abs(ref).max())), f"image {i}: {err}"
+
+
+def test_attention_peaked_rows(oracle):
+    """Large scores (|s| ~ 60): the max subtraction must keep expf in range."""
+    n, T, heads = 1, 197, 2
+    D = heads * 64
+    qkv = u(31, (T, 3 * D), 8.0)
+    got = B.attention(qkv, n, T, heads)
+    q, k, v = (np.ascontiguousarray(qkv[:, j * D:(j + 1) * D]) for j in range(3))
+    ref = oracle.attention_core(q, k, v, heads)
+    assert np.isfinite(got).all()
+    assert float(np.abs(got - ref).max()) <= 2e-4 * float(np.abs(ref).max())
+
+
+def test_attention_rejects_long_sequences():
+    qkv = np.zeros((225, 192), np.float32)
+    with pytest.raises(B.VitError):
+        B.attention(qkv, 1, 225, 1)
+
+
+# ---- patch embedding ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg,n", [(synth.VIT_TINY, 3), (synth.VIT_SMALL, 2), (synth.VIT_B16, 2)])
+def test_patch_embed(oracle, cfg, n):
+    from conftest import oracle_config
+    W = [synth.make_weight(cfg, i, 5) for i in range(4)]
+    imgs = synth.make_images(cfg, n, 6)
+    got = B.patch_embed(cfg, imgs, W[1], W[2], W[0], W[3])
+    ocfg = oracle_config(cfg)
+    for i in range(n):
+        close(got[i], oracle.embed(ocfg, imgs[i], W))
+
+
+# ---- softmax + top-1 ------------------------------------------------------------------------------
+
+def test_softmax_top1(oracle):
+    logits = u(40, (37, 1000), 6.0)
+    probs, label, prob = B.softmax_top1(logits)
+    for r in range(logits.shape[0]):
+        ref = oracle.softmax(logits[r])
+        assert float(np.abs(probs[r] - ref).max()) <= 1e-6
+        assert label[r] == int(ref.argmax())
+        assert prob[r] == probs[r, label[r]]
+    assert np.allclose(probs.sum(1), 1.0, atol=1e-5)
+
+
+def test_softmax_top1_tie_takes_first():
+    logits = np.zeros((2, 10), np.float32)
+    logits[1, 3] = logits[1, 7] = 2.0
+    _, label, _ = B.softmax_top1(logits)
+    assert list(label) == [0, 3]  # Main.c:64-68 only replaces on strictly greater

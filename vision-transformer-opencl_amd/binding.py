@@ -1,0 +1,437 @@
+"""ctypes binding of libvit_mi355x.so -- the C-ABI library is the product, this is plumbing.
+
+Everything numeric goes through the shared library (HIP kernels on gfx950).  There is no Python
+or CPU fallback: if the library has not been built, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .synth import ModelConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvit_mi355x.so")
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int)
+
+STAGES = ("embed", "ln", "qkv", "attn", "outproj", "fc1", "fc2", "head", "softmax")
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
+
+
+class VitError(RuntimeError):
+    pass
+
+
+class CConfig(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("img_size", "patch_size", "in_chans", "num_classes",
+                                       "embed_dim", "depth", "num_heads", "hidden_dim")]
+
+    @classmethod
+    def of(cls, cfg: ModelConfig) -> "CConfig":
+        return cls(cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.num_classes, cfg.embed_dim,
+                   cfg.depth, cfg.num_heads, cfg.hidden_dim)
+
+
+class CNetwork(C.Structure):  # Network.h:18-21
+    _fields_ = [("data", f32p), ("size", C.c_size_t)]
+
+
+class CImageData(C.Structure):  # Network.h:7-13
+    _fields_ = [("n", C.c_int), ("c", C.c_int), ("h", C.c_int), ("w", C.c_int), ("data", f32p)]
+
+
+class COptions(C.Structure):
+    _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int)]
+
+
+class CStageTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * len(STAGES)), ("launches", C.c_long * len(STAGES)), ("images", C.c_long)]
+
+
+class CDeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 256), ("arch", C.c_char * 64), ("compute_units", C.c_int),
+                ("clock_mhz", C.c_int), ("wavefront", C.c_int), ("lds_per_block", C.c_int),
+                ("hbm_bytes", C.c_ulonglong)]
+
+
+class CGemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int),
+                ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("epilogue", C.c_int)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the native library; never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VitError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                           "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
+                           f"{HERE}`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.vithip_error_string.restype = C.c_char_p
+        L.vit_engine_last_error.restype = C.c_char_p
+        L.vit_engine_last_error.argtypes = [C.c_void_p]
+        L.vit_engine_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CConfig), C.POINTER(COptions)]
+        L.vit_engine_destroy.argtypes = [C.c_void_p]
+        L.vit_engine_load_weights.argtypes = [C.c_void_p, C.POINTER(CNetwork), C.c_int]
+        L.vit_engine_forward_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]
+        L.vit_engine_forward_host.argtypes = [C.c_void_p, C.POINTER(f32p), C.c_int, C.POINTER(f32p)]
+        L.vit_engine_read_logits.argtypes = [C.c_void_p, f32p, C.c_int]
+        L.vit_engine_sync.argtypes = [C.c_void_p]
+        L.vit_engine_get_stage_times.argtypes = [C.c_void_p, C.POINTER(CStageTimes)]
+        L.vit_engine_reset_stage_times.argtypes = [C.c_void_p]
+        L.vit_engine_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.vit_config_weight_size.restype = C.c_size_t
+        L.vit_config_weight_size.argtypes = [C.POINTER(CConfig), C.c_int]
+        L.vit_config_macs_per_image.restype = C.c_ulonglong
+        L.vit_config_macs_per_image.argtypes = [C.POINTER(CConfig)]
+        L.vit_config_b16.restype = CConfig
+        L.load_image_data.restype = C.POINTER(CImageData)
+        L.load_image_data.argtypes = [C.c_char_p]
+        L.free_image_data.argtypes = [C.POINTER(CImageData)]
+        L.load_weights.argtypes = [C.c_char_p, C.POINTER(CNetwork), C.c_int]
+        L.free_weights.argtypes = [C.POINTER(CNetwork), C.c_int]
+        L.vit_round_weights.argtypes = [f32p, C.c_size_t]
+        L.vit_compare_results.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_float]
+        L.vit_synth_uniform.argtypes = [C.c_ulonglong, C.c_int, C.c_size_t, C.c_float, C.c_float, f32p]
+        L.vit_synth_weights.argtypes = [C.POINTER(CConfig), C.c_ulonglong, C.POINTER(CNetwork), C.c_int]
+        L.vit_synth_images.restype = C.POINTER(CImageData)
+        L.vit_synth_images.argtypes = [C.POINTER(CConfig), C.c_int, C.c_ulonglong]
+        L.vit_argmax.argtypes = [f32p, C.c_int]
+        L.ViT_hip.argtypes = [C.POINTER(CImageData), C.POINTER(CNetwork), C.POINTER(f32p)]
+        L.ViT_opencl.argtypes = [C.POINTER(CImageData), C.POINTER(CNetwork), C.POINTER(f32p)]
+        for fn in ("vithip_malloc", "vithip_host_alloc"):
+            getattr(L, fn).argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.vithip_free.argtypes = [C.c_void_p]
+        for fn in ("vithip_memcpy_h2d", "vithip_memcpy_d2h", "vithip_memcpy_d2d"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.vithip_gemm_f32.argtypes = [C.c_void_p, C.POINTER(CGemmArgs)]
+        L.vithip_patch_embed_f32.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int] * 5
+        L.vithip_layernorm_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.vithip_attention_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.vithip_softmax_top1_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.c_int]
+        L.vithip_event_create.argtypes = [C.POINTER(C.c_void_p)]
+        L.vithip_event_record.argtypes = [C.c_void_p, C.c_void_p]
+        L.vithip_event_sync.argtypes = [C.c_void_p]
+        L.vithip_event_destroy.argtypes = [C.c_void_p]
+        L.vithip_event_elapsed_ms.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        L.vithip_stream_sync.argtypes = [C.c_void_p]
+        L.vithip_get_device_info.argtypes = [C.c_int, C.POINTER(CDeviceInfo)]
+        _lib = L
+    return _lib
+
+
+def hip_check(rc: int, what: str = "HIP call") -> None:
+    if rc != 0:
+        raise VitError(f"{what}: HIP error {rc} ({lib().vithip_error_string(rc).decode()})")
+
+
+def _as_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def networks_from(weights: Sequence[np.ndarray]):
+    """(ctypes Network[count], keep-alive list).  `None` entries become {NULL, 0}."""
+    arr = (CNetwork * len(weights))()
+    keep = []
+    for i, w in enumerate(weights):
+        if w is None:
+            arr[i].data = None
+            arr[i].size = 0
+        else:
+            w = _as_f32(w)
+            keep.append(w)
+            arr[i].data = w.ctypes.data_as(f32p)
+            arr[i].size = w.size
+    return arr, keep
+
+
+# --------------------------------------------------------------------------------------------------
+# Device buffers for the op-level entry points
+# --------------------------------------------------------------------------------------------------
+class DeviceArray:
+    """A float32/int32 array in HBM owned through the C-ABI (vithip_malloc / vithip_free)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        hip_check(lib().vithip_malloc(C.byref(p), max(self.nbytes, 16)), "vithip_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        hip_check(lib().vithip_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes, None), "h2d")
+        hip_check(lib().vithip_device_sync(), "sync")
+        return d
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        hip_check(lib().vithip_device_sync(), "sync")
+        hip_check(lib().vithip_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None), "d2h")
+        hip_check(lib().vithip_device_sync(), "sync")
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().vithip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS) -> np.ndarray:
+    """C = epilogue(A . W^T + bias) through vithip_gemm_f32."""
+    A, W, bias = _as_f32(A), _as_f32(W), _as_f32(bias)
+    M, K = A.shape
+    N = W.shape[0]
+    dA, dW, db = DeviceArray.from_numpy(A), DeviceArray.from_numpy(W), DeviceArray.from_numpy(bias)
+    dC = DeviceArray((M, N))
+    dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
+    args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue)
+    hip_check(lib().vithip_gemm_f32(None, C.byref(args)), "vithip_gemm_f32")
+    return dC.numpy()
+
+
+def layernorm(x, gamma, beta) -> np.ndarray:
+    x = _as_f32(x)
+    rows, dim = x.shape
+    dx, dg, db = DeviceArray.from_numpy(x), DeviceArray.from_numpy(_as_f32(gamma)), DeviceArray.from_numpy(_as_f32(beta))
+    dy = DeviceArray((rows, dim))
+    hip_check(lib().vithip_layernorm_f32(None, dx.ptr, dim, dy.ptr, dim, dg.ptr, db.ptr, rows, dim), "vithip_layernorm_f32")
+    return dy.numpy()
+
+
+def attention(qkv, n_images: int, tokens: int, heads: int) -> np.ndarray:
+    qkv = _as_f32(qkv)
+    D = heads * 64
+    assert qkv.shape == (n_images * tokens, 3 * D)
+    dq = DeviceArray.from_numpy(qkv)
+    do = DeviceArray((n_images * tokens, D))
+    hip_check(lib().vithip_attention_f32(None, dq.ptr, do.ptr, n_images, tokens, heads), "vithip_attention_f32")
+    return do.numpy()
+
+
+def patch_embed(cfg: ModelConfig, images, conv_w, conv_b, cls, pos) -> np.ndarray:
+    images = _as_f32(images)
+    n = images.shape[0]
+    d = [DeviceArray.from_numpy(_as_f32(a)) for a in (images, conv_w, conv_b, cls, pos)]
+    dx = DeviceArray((n * cfg.tokens, cfg.embed_dim))
+    hip_check(lib().vithip_patch_embed_f32(None, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, dx.ptr, n,
+                                           cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim),
+              "vithip_patch_embed_f32")
+    return dx.numpy().reshape(n, cfg.tokens, cfg.embed_dim)
+
+
+def softmax_top1(logits):
+    logits = _as_f32(logits)
+    rows, classes = logits.shape
+    dl = DeviceArray.from_numpy(logits)
+    dp = DeviceArray((rows, classes))
+    dlab = DeviceArray((rows,), np.int32)
+    dpr = DeviceArray((rows,))
+    hip_check(lib().vithip_softmax_top1_f32(None, dl.ptr, classes, dp.ptr, classes, dlab.ptr, dpr.ptr, rows, classes),
+              "vithip_softmax_top1_f32")
+    return dp.numpy(), dlab.numpy(), dpr.numpy()
+
+
+def device_info(device: int = 0) -> dict:
+    info = CDeviceInfo()
+    hip_check(lib().vithip_get_device_info(device, C.byref(info)), "vithip_get_device_info")
+    return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
+            "clock_mhz": info.clock_mhz, "wavefront": info.wavefront, "lds_per_block": info.lds_per_block,
+            "hbm_bytes": int(info.hbm_bytes)}
+
+
+# --------------------------------------------------------------------------------------------------
+# The engine
+# --------------------------------------------------------------------------------------------------
+class Engine:
+    """vit_engine (include/vit_engine.h): weights resident in HBM, batched forward."""
+
+    def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        cc = CConfig.of(cfg)
+        opt = COptions(device, max_batch, 1 if profile else 0)
+        rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
+        if rc != 0:
+            msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"
+            if self._h:
+                lib().vit_engine_destroy(self._h)
+                self._h = C.c_void_p()
+            raise VitError(f"vit_engine_create failed ({rc}): {msg}")
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise VitError(f"{what} failed ({rc}): {lib().vit_engine_last_error(self._h).decode()}")
+
+    def load_weights(self, weights: Sequence[np.ndarray]) -> None:
+        arr, keep = networks_from(weights)
+        self._check(lib().vit_engine_load_weights(self._h, arr, len(weights)), "vit_engine_load_weights")
+
+    def forward(self, images: np.ndarray) -> np.ndarray:
+        """Host path (the ViT_opencl-shaped one): per-image pointers in, per-image rows out."""
+        images = _as_f32(images)
+        n = images.shape[0]
+        rows = [images[i] for i in range(n)]
+        probs = np.empty((n, self.cfg.num_classes), np.float32)
+        in_ptrs = (f32p * n)(*[r.ctypes.data_as(f32p) for r in rows])
+        out_ptrs = (f32p * n)(*[probs[i].ctypes.data_as(f32p) for i in range(n)])
+        self._check(lib().vit_engine_forward_host(self._h, in_ptrs, n, out_ptrs), "vit_engine_forward_host")
+        return probs
+
+    def forward_device(self, d_images: int, n: int, d_probs: int, d_label: int = 0, d_prob: int = 0,
+                       stream: int = 0) -> None:
+        """Device-resident path: raw HBM addresses (e.g. torch data_ptr()), async on `stream`."""
+        self._check(lib().vit_engine_forward_device(self._h, d_images, n, d_probs, d_label or None,
+                                                    d_prob or None, stream or None),
+                    "vit_engine_forward_device")
+
+    def sync(self) -> None:
+        self._check(lib().vit_engine_sync(self._h), "vit_engine_sync")
+
+    def logits(self, rows: int) -> np.ndarray:
+        out = np.empty((rows, self.cfg.num_classes), np.float32)
+        self._check(lib().vit_engine_read_logits(self._h, out.ctypes.data_as(f32p), rows), "vit_engine_read_logits")
+        return out
+
+    def set_profile(self, on: bool) -> None:
+        self._check(lib().vit_engine_set_profile(self._h, 1 if on else 0), "vit_engine_set_profile")
+
+    def reset_stage_times(self) -> None:
+        lib().vit_engine_reset_stage_times(self._h)
+
+    def stage_times(self) -> dict:
+        t = CStageTimes()
+        self._check(lib().vit_engine_get_stage_times(self._h, C.byref(t)), "vit_engine_get_stage_times")
+        return {"images": int(t.images),
+                "stages": {s: {"ms": float(t.ms[i]), "launches": int(t.launches[i])} for i, s in enumerate(STAGES)}}
+
+    def close(self) -> None:
+        if self._h:
+            lib().vit_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------------------
+# Facade + io
+# --------------------------------------------------------------------------------------------------
+def facade_forward(images: np.ndarray, weights: Sequence[np.ndarray], use_reference_names: bool = True) -> np.ndarray:
+    """initialize_* -> ViT_*(ImageData*, Network*, float**) -> Release_* exactly as Main.c drives it."""
+    L = lib()
+    images = _as_f32(images)
+    n, c, h, w = images.shape
+    imgs = (CImageData * n)()
+    rows = [images[i] for i in range(n)]
+    for i in range(n):
+        imgs[i] = CImageData(n, c, h, w, rows[i].ctypes.data_as(f32p))
+    nets, keep = networks_from(weights)
+    probs = np.empty((n, 1000), np.float32)
+    out_ptrs = (f32p * n)(*[probs[i].ctypes.data_as(f32p) for i in range(n)])
+    if use_reference_names:
+        L.initialize_opencl()
+        L.ViT_opencl(imgs, nets, out_ptrs)
+        L.Release_opencl()
+    else:
+        L.initialize_hip()
+        L.ViT_hip(imgs, nets, out_ptrs)
+        L.Release_hip()
+    return probs
+
+
+def load_image_file(path: str) -> Optional[np.ndarray]:
+    L = lib()
+    p = L.load_image_data(path.encode())
+    if not p:
+        return None
+    n, c, h, w = p[0].n, p[0].c, p[0].h, p[0].w
+    out = np.stack([np.ctypeslib.as_array(p[i].data, shape=(c, h, w)).copy() for i in range(n)])
+    L.free_image_data(p)
+    return out
+
+
+def load_weight_dir(directory: str, count: int):
+    """load_weights() -> list of arrays (None where the file is absent)."""
+    L = lib()
+    nets = (CNetwork * count)()
+    L.load_weights(directory.encode(), nets, count)
+    out = [np.ctypeslib.as_array(nets[i].data, shape=(nets[i].size,)).copy() if nets[i].data else None
+           for i in range(count)]
+    L.free_weights(nets, count)
+    return out
+
+
+def round_weights(w: np.ndarray) -> np.ndarray:
+    out = _as_f32(w).copy()
+    lib().vit_round_weights(out.ctypes.data_as(f32p), out.size)
+    return out
+
+
+def synth_uniform(seed: int, index: int, n: int, lo: float, hi: float) -> np.ndarray:
+    out = np.empty(n, np.float32)
+    lib().vit_synth_uniform(seed, index, n, lo, hi, out.ctypes.data_as(f32p))
+    return out
+
+
+def synth_weights_c(cfg: ModelConfig, seed: int):
+    """The C generator (vit_synth_weights); must equal synth.make_weights bit for bit."""
+    L = lib()
+    cc = CConfig.of(cfg)
+    nets = (CNetwork * cfg.n_weights)()
+    if L.vit_synth_weights(C.byref(cc), seed, nets, cfg.n_weights) != 0:
+        raise VitError("vit_synth_weights: out of memory")
+    shapes = cfg.weight_shapes()
+    out = [np.ctypeslib.as_array(nets[i].data, shape=(nets[i].size,)).copy().reshape(shapes[i])
+           for i in range(cfg.n_weights)]
+    L.free_weights(nets, cfg.n_weights)
+    return out
+
+
+def synth_images_c(cfg: ModelConfig, n: int, seed: int) -> np.ndarray:
+    L = lib()
+    cc = CConfig.of(cfg)
+    p = L.vit_synth_images(C.byref(cc), n, seed)
+    out = np.stack([np.ctypeslib.as_array(p[i].data, shape=(cfg.in_chans, cfg.img_size, cfg.img_size)).copy()
+                    for i in range(n)])
+    L.free_image_data(p)
+    return out
+
+
+def write_results(path: str, probs: np.ndarray, fix_argmax: bool = True) -> int:
+    probs = _as_f32(probs)
+    n, classes = probs.shape
+    ptrs = (f32p * n)(*[probs[i].ctypes.data_as(f32p) for i in range(n)])
+    L = lib()
+    L.vit_write_results_file.argtypes = [C.c_char_p, C.POINTER(f32p), C.c_int, C.c_int, C.c_int]
+    return L.vit_write_results_file(path.encode(), ptrs, n, classes, 1 if fix_argmax else 0)
+
+
+def compare_results(result_path: str, answer_path: str, lines: int, tol: float = 0.01) -> int:
+    return lib().vit_compare_results(result_path.encode(), answer_path.encode(), lines, tol)

@@ -1,0 +1,398 @@
+/*
+ * host/vit_engine.c -- batched ViT forward, host orchestration in C over the HIP C-ABI.
+ *
+ * Follows the stage order of the reference's forward (ViT_seq.c:337-439 / ViT_opencl.c:785-883)
+ * with the whole chunk of images as the GEMM M dimension:
+ *
+ *   patch_embed (conv_proj + flatten_transpose + class_token + pos_emb, one implicit GEMM)
+ *   depth x { LN1 -> QKV GEMM -> fused attention -> out_proj GEMM (+bias +residual, in place)
+ *             LN2 -> fc1 GEMM (+bias +GELU) -> fc2 GEMM (+bias +residual, in place) }
+ *   LN on the class-token rows only -> head GEMM -> softmax + top-1
+ *
+ * Weights are validated and uploaded once (the reference re-uploads them per op per image,
+ * e.g. ViT_opencl.c:136,630-631); activations never leave HBM between stages (the reference
+ * reads every stage back to the host).
+ */
+#include "vit_engine.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "vit_hip_kernels.h"
+
+#define MAX_EVENTS 4096   /* stage brackets kept in flight before they are read back */
+
+struct vit_engine {
+    vit_config cfg;
+    vit_engine_options opt;
+    int tokens;
+    int n_weights;
+    char err[512];
+
+    vithip_stream_t stream;      /* engine-owned in-order stream */
+    float *wblob;                /* all weights, one allocation */
+    float **w;                   /* device pointer per weight index */
+    int weights_loaded;
+
+    /* workspace for max_batch images */
+    float *x, *y, *qkv, *hbuf, *z, *logits;
+    float *in_stage;             /* device input for the host-pointer path */
+    float *out_stage;            /* device probs for the host-pointer path */
+    float *pin_in, *pin_out;     /* pinned host staging */
+    int last_rows;
+
+    /* stage profiling */
+    vithip_event_t ev[2 * MAX_EVENTS];
+    int ev_stage[MAX_EVENTS];
+    int ev_used;
+    int ev_ready;
+    long pending_images;         /* images whose brackets are still in the pool */
+    vit_stage_times times;
+};
+
+/* ------------------------------------------------------------------------------------------ */
+
+vit_config vit_config_b16(void) {
+    vit_config c = {224, 16, 3, 1000, 768, 12, 12, 3072};
+    return c;
+}
+
+int vit_config_tokens(const vit_config *cfg) {
+    int g = cfg->img_size / cfg->patch_size;
+    return g * g + 1;
+}
+
+size_t vit_config_weight_size(const vit_config *cfg, int index) {
+    const size_t D = (size_t)cfg->embed_dim, H = (size_t)cfg->hidden_dim;
+    const size_t T = (size_t)vit_config_tokens(cfg);
+    const size_t PK = (size_t)cfg->in_chans * cfg->patch_size * cfg->patch_size;
+    const int base = 4 + VIT_WEIGHTS_PER_LAYER * cfg->depth;
+    if (index < 0 || index >= base + 4) return 0;
+    if (index < 4) {
+        const size_t s[4] = {D, D * PK, D, T * D};
+        return s[index];
+    }
+    if (index >= base) {
+        const size_t s[4] = {D, D, (size_t)cfg->num_classes * D, (size_t)cfg->num_classes};
+        return s[index - base];
+    }
+    {
+        /* ln1 w,b | in_proj w,b | out_proj w,b | ln2 w,b | fc1 w,b | fc2 w,b  (ViT_seq.c:366-426) */
+        const size_t s[12] = {D, D, 3 * D * D, 3 * D, D * D, D, D, D, H * D, H, D * H, D};
+        return s[(index - 4) % VIT_WEIGHTS_PER_LAYER];
+    }
+}
+
+unsigned long long vit_config_macs_per_image(const vit_config *cfg) {
+    const unsigned long long T = (unsigned long long)vit_config_tokens(cfg), D = cfg->embed_dim,
+                             H = cfg->hidden_dim, hd = D / cfg->num_heads,
+                             PK = (unsigned long long)cfg->in_chans * cfg->patch_size * cfg->patch_size;
+    const unsigned long long layer = T * D * 3 * D + 2 * cfg->num_heads * T * T * hd + T * D * D + 2 * T * D * H;
+    return (T - 1) * PK * D + cfg->depth * layer + D * cfg->num_classes;
+}
+
+void vit_engine_default_options(vit_engine_options *opt) {
+    opt->device = 0;
+    opt->max_batch = 256;
+    opt->profile = 0;
+}
+
+static int fail(vit_engine *e, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e->err, sizeof(e->err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                     \
+    do {                                                                                     \
+        int rc_ = (call);                                                                    \
+        if (rc_ != 0)                                                                        \
+            return fail((e), VIT_ERR_HIP, "[%s:%d] HIP error %d (%s) in %s", __FILE__, __LINE__, \
+                        rc_, vithip_error_string(rc_), #call);                               \
+    } while (0)
+
+const char *vit_engine_last_error(const vit_engine *e) { return e ? e->err : "null engine"; }
+const vit_config *vit_engine_config(const vit_engine *e) { return &e->cfg; }
+
+static int check_config(vit_engine *e) {
+    const vit_config *c = &e->cfg;
+    if (c->img_size <= 0 || c->patch_size <= 0 || c->in_chans <= 0 || c->num_classes <= 0 ||
+        c->embed_dim <= 0 || c->depth <= 0 || c->num_heads <= 0 || c->hidden_dim <= 0)
+        return fail(e, VIT_ERR_ARG, "vit_config: all dimensions must be positive");
+    if (c->img_size % c->patch_size) return fail(e, VIT_ERR_ARG, "img_size must be a multiple of patch_size");
+    if (c->embed_dim % c->num_heads || c->embed_dim / c->num_heads != 64)
+        return fail(e, VIT_ERR_ARG, "HIP attention kernel needs head_dim == 64 (got %d/%d)", c->embed_dim, c->num_heads);
+    if (c->embed_dim % 32 || c->hidden_dim % 32)
+        return fail(e, VIT_ERR_ARG, "embed_dim and hidden_dim must be multiples of 32");
+    if (c->patch_size % 4 || c->img_size % 4 || (c->in_chans * c->patch_size * c->patch_size) % 32)
+        return fail(e, VIT_ERR_ARG, "patch geometry unsupported (patch%%4, img%%4, C*P*P%%32 must be 0)");
+    if (vit_config_tokens(c) > 224)
+        return fail(e, VIT_ERR_ARG, "more than 224 tokens (%d): K/V-tiled attention is not built yet", vit_config_tokens(c));
+    if (c->embed_dim > 2048) return fail(e, VIT_ERR_ARG, "embed_dim > 2048 unsupported by the LayerNorm kernel");
+    return VIT_OK;
+}
+
+int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_options *opt) {
+    static vit_engine scratch;  /* error text holder when allocation itself fails */
+    if (!out) return VIT_ERR_ARG;
+    *out = NULL;
+    vit_engine *e = (vit_engine *)calloc(1, sizeof(*e));
+    if (!e) return fail(&scratch, VIT_ERR_NOMEM, "out of host memory");
+    *out = e; /* returned even on failure so the caller can read the message, then destroy */
+    e->cfg = cfg ? *cfg : vit_config_b16();
+    if (opt) e->opt = *opt; else vit_engine_default_options(&e->opt);
+    if (e->opt.max_batch <= 0) e->opt.max_batch = 256;
+    int rc = check_config(e);
+    if (rc) return rc;
+    e->tokens = vit_config_tokens(&e->cfg);
+    e->n_weights = VIT_WEIGHT_COUNT(e->cfg.depth);
+
+    int ndev = 0;
+    HIP_TRY(e, vithip_device_count(&ndev));
+    if (e->opt.device < 0 || e->opt.device >= ndev)
+        return fail(e, VIT_ERR_ARG, "device %d not available (%d HIP devices)", e->opt.device, ndev);
+    HIP_TRY(e, vithip_set_device(e->opt.device));
+    HIP_TRY(e, vithip_stream_create(&e->stream));
+
+    const size_t B = (size_t)e->opt.max_batch, T = (size_t)e->tokens, D = (size_t)e->cfg.embed_dim,
+                 H = (size_t)e->cfg.hidden_dim, NC = (size_t)e->cfg.num_classes;
+    const size_t img = (size_t)e->cfg.in_chans * e->cfg.img_size * e->cfg.img_size;
+    HIP_TRY(e, vithip_malloc((void **)&e->x, B * T * D * sizeof(float)));
+    HIP_TRY(e, vithip_malloc((void **)&e->y, B * T * D * sizeof(float)));
+    HIP_TRY(e, vithip_malloc((void **)&e->qkv, B * T * 3 * D * sizeof(float)));
+    HIP_TRY(e, vithip_malloc((void **)&e->hbuf, B * T * H * sizeof(float)));
+    HIP_TRY(e, vithip_malloc((void **)&e->z, B * D * sizeof(float)));
+    HIP_TRY(e, vithip_malloc((void **)&e->logits, B * NC * sizeof(float)));
+    HIP_TRY(e, vithip_malloc((void **)&e->in_stage, B * img * sizeof(float)));
+    HIP_TRY(e, vithip_malloc((void **)&e->out_stage, B * NC * sizeof(float)));
+    HIP_TRY(e, vithip_host_alloc((void **)&e->pin_in, B * img * sizeof(float)));
+    HIP_TRY(e, vithip_host_alloc((void **)&e->pin_out, B * NC * sizeof(float)));
+
+    e->w = (float **)calloc((size_t)e->n_weights, sizeof(float *));
+    if (!e->w) return fail(e, VIT_ERR_NOMEM, "out of host memory");
+    if (e->opt.profile) return vit_engine_set_profile(e, 1);
+    return VIT_OK;
+}
+
+void vit_engine_destroy(vit_engine *e) {
+    if (!e) return;
+    if (e->stream) vithip_stream_sync(e->stream);
+    if (e->ev_ready)
+        for (int i = 0; i < 2 * MAX_EVENTS; ++i) vithip_event_destroy(e->ev[i]);
+    vithip_free(e->x); vithip_free(e->y); vithip_free(e->qkv); vithip_free(e->hbuf);
+    vithip_free(e->z); vithip_free(e->logits); vithip_free(e->in_stage); vithip_free(e->out_stage);
+    vithip_free(e->wblob);
+    if (e->pin_in) vithip_host_free(e->pin_in);
+    if (e->pin_out) vithip_host_free(e->pin_out);
+    if (e->stream) vithip_stream_destroy(e->stream);
+    free(e->w);
+    free(e);
+}
+
+int vit_engine_set_profile(vit_engine *e, int on) {
+    if (on && !e->ev_ready) {
+        for (int i = 0; i < 2 * MAX_EVENTS; ++i) HIP_TRY(e, vithip_event_create(&e->ev[i]));
+        e->ev_ready = 1;
+    }
+    e->opt.profile = on ? 1 : 0;
+    return VIT_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+
+int vit_engine_load_weights(vit_engine *e, const Network *weights, int count) {
+    if (!e || !weights) return e ? fail(e, VIT_ERR_ARG, "null weights") : VIT_ERR_ARG;
+    if (count != e->n_weights)
+        return fail(e, VIT_ERR_WEIGHTS, "expected %d weight tensors for depth %d, got %d", e->n_weights, e->cfg.depth, count);
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) {
+        const size_t want = vit_config_weight_size(&e->cfg, i);
+        if (!weights[i].data)
+            return fail(e, VIT_ERR_WEIGHTS, "weight %d is missing (Network[%d].data == NULL; expected %zu floats)", i, i, want);
+        if (weights[i].size != want)
+            return fail(e, VIT_ERR_WEIGHTS, "weight %d has %zu floats, expected %zu", i, weights[i].size, want);
+        total += (want + 63) & ~(size_t)63; /* 256-byte aligned slots */
+    }
+    HIP_TRY(e, vithip_set_device(e->opt.device));
+    if (e->wblob) { vithip_stream_sync(e->stream); vithip_free(e->wblob); e->wblob = NULL; }
+    HIP_TRY(e, vithip_malloc((void **)&e->wblob, total * sizeof(float)));
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) {
+        e->w[i] = e->wblob + off;
+        HIP_TRY(e, vithip_memcpy_h2d(e->w[i], weights[i].data, weights[i].size * sizeof(float), e->stream));
+        off += (weights[i].size + 63) & ~(size_t)63;
+    }
+    HIP_TRY(e, vithip_stream_sync(e->stream));
+    e->weights_loaded = 1;
+    return VIT_OK;
+}
+
+/* ---- stage launch helpers -------------------------------------------------------------------- */
+
+static int stage_begin(vit_engine *e, vithip_stream_t s, int stage) {
+    if (!e->opt.profile || e->ev_used >= MAX_EVENTS) return 0;
+    e->ev_stage[e->ev_used] = stage;
+    return vithip_event_record(e->ev[2 * e->ev_used], s);
+}
+static int stage_end(vit_engine *e, vithip_stream_t s) {
+    if (!e->opt.profile || e->ev_used >= MAX_EVENTS) return 0;
+    int rc = vithip_event_record(e->ev[2 * e->ev_used + 1], s);
+    e->ev_used++;
+    return rc;
+}
+
+static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int lda, const float *W,
+                const float *bias, const float *res, float *C, int ldc, int M, int N, int K, int epi) {
+    vithip_gemm_args a;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
+    a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
+    HIP_TRY(e, stage_begin(e, s, stage));
+    HIP_TRY(e, vithip_gemm_f32(s, &a));
+    HIP_TRY(e, stage_end(e, s));
+    return VIT_OK;
+}
+
+static int collect_profile(vit_engine *e) {
+    if (e->ev_used == 0) return VIT_OK;
+    HIP_TRY(e, vithip_event_sync(e->ev[2 * (e->ev_used - 1) + 1]));
+    for (int i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(e, vithip_event_elapsed_ms(&ms, e->ev[2 * i], e->ev[2 * i + 1]));
+        e->times.ms[e->ev_stage[i]] += ms;
+        e->times.launches[e->ev_stage[i]]++;
+    }
+    e->times.images += e->pending_images;
+    e->pending_images = 0;
+    e->ev_used = 0;
+    return VIT_OK;
+}
+
+/* One chunk of nb <= max_batch images, everything device resident. */
+static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images, int nb, float *d_probs,
+                         int *d_label, float *d_prob) {
+    const vit_config *c = &e->cfg;
+    const int T = e->tokens, D = c->embed_dim, H = c->hidden_dim, M = nb * T;
+    float **w = e->w;
+    int rc;
+
+    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_EMBED));
+    HIP_TRY(e, vithip_patch_embed_f32(s, d_images, w[1], w[2], w[0], w[3], e->x, nb, c->img_size,
+                                      c->patch_size, c->in_chans, D));
+    HIP_TRY(e, stage_end(e, s));
+
+    for (int l = 0; l < c->depth; ++l) {
+        float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
+        /* LN1 (ViT_seq.c:281) */
+        HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(s, e->x, (size_t)D, e->y, (size_t)D, lw[0], lw[1], M, D));
+        HIP_TRY(e, stage_end(e, s));
+        /* QKV in_proj (ViT_seq.c:134-147) */
+        if ((rc = gemm(e, s, VIT_STAGE_QKV, e->y, D, lw[2], lw[3], NULL, e->qkv, 3 * D, M, 3 * D, D, VITHIP_EPI_BIAS))) return rc;
+        /* scores, softmax, P.V (ViT_seq.c:156-215) -> y */
+        HIP_TRY(e, stage_begin(e, s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_f32(s, e->qkv, e->y, nb, T, c->num_heads));
+        HIP_TRY(e, stage_end(e, s));
+        /* out_proj + residual (ViT_seq.c:219-227,286-288): x = x + (y.Wo^T + bo) */
+        if ((rc = gemm(e, s, VIT_STAGE_OUTPROJ, e->y, D, lw[4], lw[5], e->x, e->x, D, M, D, D, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
+        /* LN2 (ViT_seq.c:291) */
+        HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(s, e->x, (size_t)D, e->y, (size_t)D, lw[6], lw[7], M, D));
+        HIP_TRY(e, stage_end(e, s));
+        /* fc1 + GELU (ViT_seq.c:258-264) */
+        if ((rc = gemm(e, s, VIT_STAGE_FC1, e->y, D, lw[8], lw[9], NULL, e->hbuf, H, M, H, D, VITHIP_EPI_BIAS_GELU))) return rc;
+        /* fc2 + residual (ViT_seq.c:266,297-299): x = x + (h.W2^T + b2) */
+        if ((rc = gemm(e, s, VIT_STAGE_FC2, e->hbuf, H, lw[10], lw[11], e->x, e->x, D, M, D, H, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
+    }
+
+    /* final LayerNorm on the class-token rows only (ViT_seq.c:429-433 normalises all rows, uses row 0) */
+    float **fw = w + 4 + VIT_WEIGHTS_PER_LAYER * c->depth;
+    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
+    HIP_TRY(e, vithip_layernorm_f32(s, e->x, (size_t)T * D, e->z, (size_t)D, fw[0], fw[1], nb, D));
+    HIP_TRY(e, stage_end(e, s));
+    /* classifier head (ViT_seq.c:435) */
+    if ((rc = gemm(e, s, VIT_STAGE_HEAD, e->z, D, fw[2], fw[3], NULL, e->logits, c->num_classes, nb, c->num_classes, D, VITHIP_EPI_BIAS))) return rc;
+    /* Softmax (ViT_seq.c:437) + top-1 (Main.c:62-70) */
+    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_SOFTMAX));
+    HIP_TRY(e, vithip_softmax_top1_f32(s, e->logits, c->num_classes, d_probs, c->num_classes, d_label, d_prob, nb, c->num_classes));
+    HIP_TRY(e, stage_end(e, s));
+    e->last_rows = nb;
+    return VIT_OK;
+}
+
+int vit_engine_forward_device(vit_engine *e, const float *d_images, int n, float *d_probs,
+                              int *d_top1_label, float *d_top1_prob, void *stream) {
+    if (!e) return VIT_ERR_ARG;
+    if (!d_images || !d_probs || n <= 0) return fail(e, VIT_ERR_ARG, "forward_device: bad arguments (n=%d)", n);
+    if (!e->weights_loaded) return fail(e, VIT_ERR_STATE, "forward before vit_engine_load_weights()");
+    vithip_stream_t s = stream ? (vithip_stream_t)stream : e->stream;
+    const size_t img = (size_t)e->cfg.in_chans * e->cfg.img_size * e->cfg.img_size;
+    const size_t NC = (size_t)e->cfg.num_classes;
+    for (int done = 0; done < n; done += e->opt.max_batch) {
+        const int nb = n - done < e->opt.max_batch ? n - done : e->opt.max_batch;
+        int rc = forward_chunk(e, s, d_images + (size_t)done * img, nb, d_probs + (size_t)done * NC,
+                               d_top1_label ? d_top1_label + done : NULL,
+                               d_top1_prob ? d_top1_prob + done : NULL);
+        if (rc) return rc;
+        if (e->opt.profile) e->pending_images += nb;
+        /* read the brackets back lazily (it needs an event sync): only when the pool runs low */
+        if (e->opt.profile && e->ev_used > MAX_EVENTS - 256 && (rc = collect_profile(e))) return rc;
+    }
+    return VIT_OK;
+}
+
+int vit_engine_sync(vit_engine *e) {
+    if (!e) return VIT_ERR_ARG;
+    HIP_TRY(e, vithip_stream_sync(e->stream));
+    return VIT_OK;
+}
+
+int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, float *const *probs) {
+    if (!e) return VIT_ERR_ARG;
+    if (!images || !probs || n <= 0) return fail(e, VIT_ERR_ARG, "forward_host: bad arguments (n=%d)", n);
+    if (!e->weights_loaded) return fail(e, VIT_ERR_STATE, "forward before vit_engine_load_weights()");
+    const size_t img = (size_t)e->cfg.in_chans * e->cfg.img_size * e->cfg.img_size;
+    const size_t NC = (size_t)e->cfg.num_classes;
+    for (int i = 0; i < n; ++i)
+        if (!images[i] || !probs[i]) return fail(e, VIT_ERR_ARG, "forward_host: image or output row %d is NULL", i);
+    HIP_TRY(e, vithip_set_device(e->opt.device));
+    for (int done = 0; done < n; done += e->opt.max_batch) {
+        const int nb = n - done < e->opt.max_batch ? n - done : e->opt.max_batch;
+        for (int i = 0; i < nb; ++i) memcpy(e->pin_in + (size_t)i * img, images[done + i], img * sizeof(float));
+        HIP_TRY(e, vithip_memcpy_h2d(e->in_stage, e->pin_in, (size_t)nb * img * sizeof(float), e->stream));
+        int rc = forward_chunk(e, e->stream, e->in_stage, nb, e->out_stage, NULL, NULL);
+        if (rc) return rc;
+        HIP_TRY(e, vithip_memcpy_d2h(e->pin_out, e->out_stage, (size_t)nb * NC * sizeof(float), e->stream));
+        HIP_TRY(e, vithip_stream_sync(e->stream));
+        if (e->opt.profile) e->pending_images += nb;
+        if (e->opt.profile && (rc = collect_profile(e))) return rc;
+        for (int i = 0; i < nb; ++i) memcpy(probs[done + i], e->pin_out + (size_t)i * NC, NC * sizeof(float));
+    }
+    return VIT_OK;
+}
+
+int vit_engine_read_logits(vit_engine *e, float *dst, int rows) {
+    if (!e || !dst) return VIT_ERR_ARG;
+    if (rows <= 0 || rows > e->last_rows) return fail(e, VIT_ERR_ARG, "read_logits: %d rows requested, last chunk had %d", rows, e->last_rows);
+    HIP_TRY(e, vithip_device_sync()); /* the chunk may have run on a caller-provided stream */
+    HIP_TRY(e, vithip_memcpy_d2h(dst, e->logits, (size_t)rows * e->cfg.num_classes * sizeof(float), e->stream));
+    HIP_TRY(e, vithip_stream_sync(e->stream));
+    return VIT_OK;
+}
+
+int vit_engine_get_stage_times(vit_engine *e, vit_stage_times *out) {
+    if (!e || !out) return VIT_ERR_ARG;
+    int rc = collect_profile(e);
+    if (rc) return rc;
+    *out = e->times;
+    return VIT_OK;
+}
+
+void vit_engine_reset_stage_times(vit_engine *e) {
+    if (!e) return;
+    collect_profile(e); /* drain the pool so earlier brackets do not leak into the next window */
+    memset(&e->times, 0, sizeof(e->times));
+}
