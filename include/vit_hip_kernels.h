@@ -95,8 +95,19 @@ typedef struct {
     int epilogue;
 } vithip_gemm_args;
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
-/* Tuning hook for benchmarks: workgroup tile 0/1 = 128x128 (default), 2 = 256x128, 3 = 128x64. */
+/* Tuning hook for benchmarks.  0 = default (128x128 tile, K step 32, software-pipelined loop);
+ * classic loop: 1 = 128x128, 2 = 256x128, 3 = 128x64, 4 = 128x128 K16, 5 = 128x64 K16;
+ * pipelined loop: 6 = 128x128 K16, 7 = 256x128, 8 = 128x64;
+ * 101-105 = timing-only probe builds of the classic 128x128 kernel (wrong results by construction). */
 int vithip_gemm_set_tile(int tile);
+/* Tuning hook: tile rows per L2 group of the tile walk (default 8; 1 = plain N-fastest order). */
+int vithip_gemm_set_group(int group_m);
+
+/* Measurement probe: register-only fp32 MFMA loop; each wave issues iters*32 v_mfma_f32_32x32x2_f32
+ * (4096 flop each).  Used by tools/gemm_probe.py to read the sustained matrix clock. */
+int vithip_probe_mfma_f32(vithip_stream_t stream, float *out, int blocks, int threads, int iters);
+/* Waves 0-3 of every 512-thread block issue iters*32 MFMAs, waves 4-7 valu_iters*64 independent v_fma_f32. */
+int vithip_probe_mfma_vs_valu(vithip_stream_t stream, float *out, int blocks, int iters, int valu_iters);
 
 /*
  * Patch embedding straight from NCHW images (implicit GEMM over the 16x16 patches), with the

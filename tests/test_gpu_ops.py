@@ -62,7 +62,7 @@ def test_gemm_bias_residual(oracle):
     close(B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL), ref)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_tile_variants(oracle, tile):
     M, N, K = 515, 200, 96
     A, W, b = u(12, (M, K), 1.0), u(13, (N, K), 0.1), u(14, (N,), 0.1)
@@ -162,3 +162,17 @@ def test_softmax_top1_tie_takes_first():
     logits[1, 3] = logits[1, 7] = 2.0
     _, label, _ = B.softmax_top1(logits)
     assert list(label) == [0, 3]  # Main.c:64-68 only replaces on strictly greater
+
+
+def test_gelu_epilogue_matches_libm_erf_over_range(oracle):
+    """The kernel's polynomial erf against the oracle's erff on a dense sweep of pre-activations
+    (-8..8): one GEMM with K = 32 whose single non-zero product passes the sweep value through."""
+    n = 4096
+    xs = np.linspace(-8.0, 8.0, n).astype(np.float32)
+    A = np.zeros((n, 32), np.float32)
+    A[:, 0] = xs
+    W = np.zeros((32, 32), np.float32)
+    W[:, 0] = 1.0
+    got = B.gemm(A, W, np.zeros(32, np.float32), epilogue=B.EPI_BIAS_GELU)[:, 0]
+    ref = oracle.gelu(xs)
+    assert float(np.abs(got - ref).max()) <= 1e-6

@@ -1,0 +1,87 @@
+// csrc/vit_probe.hip -- measurement probes (not on the forward path).
+//
+// vithip_probe_mfma_f32: a register-only v_mfma_f32_32x32x2_f32 loop, 4 independent accumulators
+// per wave, to read the fp32 matrix rate (and so the clock) the chip sustains; the GEMM roofline
+// fraction in bench.py is quoted against the spec peak, this probe says how much of the gap is
+// the kernel's and how much the clock's.
+#include <hip/hip_runtime.h>
+
+#include "vit_hip_kernels.h"
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void mfma_f32_loop_kernel(float *out, int iters, float seed) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s += acc[i][v];
+    if (s == 12345.678f) out[0] = s;  // keep the chain alive without a store on the common path
+}
+
+// Waves 0-3 of each 512-thread block run the MFMA loop, waves 4-7 a dependent-free v_fma_f32 loop of
+// `valu_iters` x 64 instructions: does fp32 VALU work on the partner wave slow the fp32 matrix pipe?
+__global__ __launch_bounds__(512) void mfma_vs_valu_kernel(float *out, int iters, int valu_iters, float seed) {
+    const int wave = threadIdx.x >> 6;
+    if (wave < 4) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+        float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 1e-3f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s += acc[i][v];
+        if (s == 12345.678f) out[0] = s;
+    } else {
+        float x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = seed * (i + 1) + threadIdx.x * 1e-4f;
+        for (int it = 0; it < valu_iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] = fmaf(x[i], 0.999f, 0.001f);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += x[i];
+        if (s == 12345.678f) out[1] = s;
+    }
+}
+}  // namespace
+
+extern "C" int vithip_probe_mfma_vs_valu(vithip_stream_t stream, float *out, int blocks, int iters, int valu_iters) {
+    hipLaunchKernelGGL(mfma_vs_valu_kernel, dim3(blocks), dim3(512), 0, static_cast<hipStream_t>(stream), out, iters,
+                       valu_iters, 0.37f);
+    return static_cast<int>(hipGetLastError());
+}
+
+// Launches blocks x threads; every wave issues iters*32 MFMAs (iters*32*4096 flop).
+extern "C" int vithip_probe_mfma_f32(vithip_stream_t stream, float *out, int blocks, int threads, int iters) {
+    hipLaunchKernelGGL(mfma_f32_loop_kernel, dim3(blocks), dim3(threads), 0, static_cast<hipStream_t>(stream), out,
+                       iters, 0.37f);
+    return static_cast<int>(hipGetLastError());
+}
