@@ -57,6 +57,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (metric config: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per step (engine option)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
     args = ap.parse_args()
 
@@ -87,7 +88,7 @@ def main() -> None:
     B = args.batch
     binding.lib().vithip_gemm_set_tile(args.gemm_tile)
     weights = synth.make_weights(cfg, 1234)
-    eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=True)
+    eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=True, lanes=args.lanes)
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the

@@ -35,6 +35,7 @@ typedef struct {
     int device;      /* HIP device ordinal */
     int max_batch;   /* images per forward chunk (workspace is sized for it); default 256 */
     int profile;     /* 1: bracket every stage with events and accumulate vit_stage_times */
+    int lanes;       /* sub-batches of a chunk run concurrently on separate streams (1..4); default 1 */
 } vit_engine_options;
 
 /* Per-stage device time of the profiled forwards (ms, summed) and launch counts. */
@@ -93,6 +94,7 @@ int vit_engine_read_logits(vit_engine *e, float *dst, int rows);
 int vit_engine_get_stage_times(vit_engine *e, vit_stage_times *out);  /* syncs, then reports */
 void vit_engine_reset_stage_times(vit_engine *e);
 int vit_engine_set_profile(vit_engine *e, int on);
+int vit_engine_set_lanes(vit_engine *e, int lanes);
 
 #ifdef __cplusplus
 }

@@ -147,3 +147,17 @@ def test_stage_profile_counts_launches():
     assert t["stages"]["ln"]["launches"] == 2 * cfg.depth + 1
     assert all(v["ms"] >= 0 for v in t["stages"].values())
     eng.close()
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_concurrent_lanes_give_identical_results(b16, lanes):
+    """Sub-batches on separate streams (engine option `lanes`) must not change a single bit."""
+    eng, W = b16
+    imgs = synth.make_images(synth.VIT_B16, 7, 4321)
+    ref = eng.forward(imgs)
+    eng.set_lanes(lanes)
+    try:
+        got = eng.forward(imgs)
+    finally:
+        eng.set_lanes(1)
+    assert np.array_equal(got, ref)

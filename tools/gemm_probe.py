@@ -84,6 +84,21 @@ def main():
             B.hip_check(L.vithip_gemm_set_tile(args.stamp_tile))
             ms105 = timed(lambda: B.hip_check(L.vithip_gemm_f32(None, C.byref(ga))))
             d = dbg.numpy().astype(np.int64)
+            if args.stamp_tile == 129:  # persistent kernel: [start, loop start, sum of epilogues, end, rt0, rt1, tiles, steps]
+                d = d[d[:, 7] > 0]
+                tot, epi, steps, tiles = d[:, 3] - d[:, 0], d[:, 2], d[:, 7], d[:, 6]
+                clk = tot / np.maximum((d[:, 5] - d[:, 4]).astype(np.float64), 1) * 100.0
+                print(json.dumps({name + "_persistent_stamps": {
+                    "event_ms": round(ms105, 3), "wgs": int(len(d)), "span_us": round(float((d[:, 5].max() - d[:, 4].min()) / 100.0), 1),
+                    "clock_mhz_median": round(float(np.median(clk))), "wg_total_cycles_median": int(np.median(tot)),
+                    "prologue_cycles_median": int(np.median(d[:, 1] - d[:, 0])),
+                    "cycles_per_step_median": round(float(np.median((d[:, 3] - d[:, 1] - epi) / steps))),
+                    "epilogue_cycles_per_tile_median": round(float(np.median(epi / tiles))),
+                    "tiles_per_wg": [int(tiles.min()), int(tiles.max())]}}))
+                L.vithip_gemm_set_debug_buffer(None)
+                dbg.free()
+                L.vithip_gemm_set_tile(0)
+                continue
             tot, pro, loop, epi = d[:, 3] - d[:, 0], d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]
             rt = (d[:, 5] - d[:, 4]).astype(np.float64)  # 100 MHz ticks
             clk = tot / np.maximum(rt, 1) * 100.0  # MHz

@@ -14,3 +14,14 @@ for valu_iters in (0, 16000, 32000, 64000, 128000):
     ms = timed(lambda: B.hip_check(L.vithip_probe_mfma_vs_valu(None, out.ptr, 256, iters, valu_iters)), reps=3, warm=1)
     res[valu_iters] = {"ms": round(ms, 3), "mfma_cycles_M": iters * 32 * 64 / 1e6, "valu_instr_M": valu_iters * 64 / 1e6}
 print(json.dumps(res))
+
+L.vithip_probe_mfma_vs_gelu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+res = {}
+for mode in (0, 1):
+    for mf in (0, 4000):
+        for gi in (0, 20000):
+            if mf == 0 and gi == 0:
+                continue
+            ms = timed(lambda: B.hip_check(L.vithip_probe_mfma_vs_gelu(None, out.ptr, 256, mf, gi, mode)), reps=3, warm=1)
+            res[f"mode{mode}_mfma{mf}_gelu{gi}"] = round(ms, 3)
+print(json.dumps({"gelu_probe_ms (8 gelu per iter per lane)": res}))

@@ -46,7 +46,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 
 
 class COptions(C.Structure):
-    _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int)]
+    _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -269,11 +269,12 @@ def device_info(device: int = 0) -> dict:
 class Engine:
     """vit_engine (include/vit_engine.h): weights resident in HBM, batched forward."""
 
-    def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False):
+    def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
+                 lanes: int = 1):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
-        opt = COptions(device, max_batch, 1 if profile else 0)
+        opt = COptions(device, max_batch, 1 if profile else 0, lanes)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"
@@ -315,6 +316,11 @@ class Engine:
         out = np.empty((rows, self.cfg.num_classes), np.float32)
         self._check(lib().vit_engine_read_logits(self._h, out.ctypes.data_as(f32p), rows), "vit_engine_read_logits")
         return out
+
+    def set_lanes(self, lanes: int) -> None:
+        L = lib()
+        L.vit_engine_set_lanes.argtypes = [C.c_void_p, C.c_int]
+        self._check(L.vit_engine_set_lanes(self._h, lanes), "vit_engine_set_lanes")
 
     def set_profile(self, on: bool) -> None:
         self._check(lib().vit_engine_set_profile(self._h, 1 if on else 0), "vit_engine_set_profile")

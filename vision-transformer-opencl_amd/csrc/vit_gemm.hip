@@ -27,86 +27,20 @@
 //    XCD's L2 once and reused by all its N tiles.
 //  * The implicit-GEMM variant (patch embedding) gathers A straight from NCHW images and
 //    fuses "+ pos_emb" and the token-row remap into the store.
-#include <hip/hip_runtime.h>
+#include "vit_gemm_common.hpp"
 
-#include "vit_hip_kernels.h"
+namespace vitgemm {
+int launch_persistent(hipStream_t stream, GemmParams &p, int epilogue, int group_m);  // vit_gemm_persistent.hip
+int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, int group_m);
+}
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int KALIGN = 32;  // K must be a multiple of this (covers both K steps below)
-
-enum { A_DENSE = 0, A_PATCHES = 1 };
+using namespace vitgemm;
 
 int g_gemm_tile = 0;   // 0 = auto; see vithip_gemm_set_tile()
 int g_gemm_group = 8;  // tile rows per L2 group; see vithip_gemm_set_group()
 unsigned long long *g_gemm_dbg = nullptr;  // stamp buffer of the DBG == 5 probe
-
-struct GemmParams {
-    const float *A;
-    const float *W;
-    const float *bias;
-    const float *R;
-    float *C;
-    int lda, ldw, ldr, ldc;
-    int M, N, K;
-    int tiles_m, tiles_n;
-    int group_m;     // tile rows per L2 group (see tile_coords)
-    // A_PATCHES only
-    const float *pos;
-    unsigned long long *dbg;  // DBG == 5: 8 stamps per workgroup
-    int patches;     // patches per image (G*G)
-    int grid;        // G = img/patch
-    int patch;       // P
-    int img;         // S
-    int chans;       // C
-};
-
-// erf(x) = sign(x) * (1 - exp(t*q(t))), t = min(|x|, 4), q = degree-7 minimax fit of log(erfc(t))/t
-// (fitted against scipy.special.erf; max |error| 1.2e-7 when evaluated in fp32, i.e. fp32 rounding
-// noise -- libm's erff costs ~45 VALU instructions and two divergent branches per element, which made
-// the fc1 epilogue 10 % of that GEMM; this form is 14 straight-line instructions).
-__device__ __forceinline__ float erf_fp32(float x) {
-    const float t = fminf(fabsf(x), 4.0f);
-    float q = -3.144179208902642e-05f;
-    q = fmaf(q, t, 3.0881378916092217e-04f);
-    q = fmaf(q, t, -1.0324339382350445e-03f);
-    q = fmaf(q, t, -5.368884885683656e-04f);
-    q = fmaf(q, t, 1.95839274674654e-02f);
-    q = fmaf(q, t, -1.0291960090398788e-01f);
-    q = fmaf(q, t, -6.36597752571106e-01f);
-    q = fmaf(q, t, -1.128380298614502f);
-    const float e = __builtin_amdgcn_exp2f(q * t * 1.4426950408889634f);  // v_exp_f32
-    return copysignf(1.0f - e, x);
-}
-
-// GELU of the reference: 0.5f * x * (1.0f + erff(x / sqrtf(2.0f)))  (ViT_seq.c:231-233)
-__device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erf_fp32(x * 0.70710678118654752440f));
-}
-
-// Workgroup id -> tile id such that ids sharing an XCD (id % 8) get consecutive tiles.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, rem = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    return base + idx;
-}
-
-// Tile id -> (tm, tn).  Tiles are walked in groups of `group_m` tile rows: inside a group the id
-// runs down the rows first, then across the columns, so the ~64 workgroups resident on one XCD
-// cover a compact group_m x (64/group_m) block of tiles and share both their A row-panels and their
-// W column-panels through that XCD's 4 MB L2 (instead of sweeping all of W per A panel).
-__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int group_m, int &tm, int &tn) {
-    const int per_group = group_m * tiles_n;
-    const int g = tile / per_group, in_g = tile - g * per_group;
-    const int first = g * group_m;
-    const int rows = tiles_m - first < group_m ? tiles_m - first : group_m;
-    tn = in_g / rows;
-    tm = first + (in_g - tn * rows);
-}
 
 // DBG != 0 builds timing-only probes (tools/gemm_probe.py): 1 = no global loads and no LDS stores in
 // the K loop, 2 = no global loads, 3 = no LDS stores, 4 = as 1 without the barrier.  Results are wrong
@@ -341,92 +275,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
     }
 
     if constexpr (DBG == 5) st_clk2 = __builtin_amdgcn_s_memtime();
-    // ---- epilogue -----------------------------------------------------------------------------
-    // A lane holds column n of 16 rows per accumulator; each store instruction writes two 128-B
-    // row segments.  vmcnt counts stores as well as loads, so any load that is waited for between
-    // stores serialises them on the full write latency (measured: 70k cycles per tile, 29 % of the
-    // kernel).  Hence: bias was fetched before the K loop, interior tiles take a branch-free path,
-    // and the residual / pos_emb operands of one accumulator are all loaded before its 16 stores.
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);  // workgroup-uniform
-    if (interior) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + r;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mb = m0 + wm * WM + i * 32 + 4 * h;  // row of register 0
-                if constexpr (AMODE == A_PATCHES) {
-                    float add[16];
-                    size_t orow[16];
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int m = mb + (v & 3) + 8 * (v >> 2);
-                        const int im = m / p.patches, pp = m - im * p.patches;
-                        add[v] = p.pos[(size_t)(pp + 1) * p.N + n];
-                        orow[v] = (size_t)m + im + 1;
-                    }
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) p.C[orow[v] * p.ldc + n] = acc[i][j][v] + bias_r[j] + add[v];
-                } else {
-                    float *crow = p.C + (size_t)mb * p.ldc + n;
-                    if constexpr (EPI == VITHIP_EPI_BIAS_RESIDUAL) {
-                        const float *rrow = p.R + (size_t)mb * p.ldr + n;
-                        // two batches of 8 loads-then-stores: enough in flight, half the registers
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            float res[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int v = half * 8 + q;
-                                res[q] = rrow[(size_t)((v & 3) + 8 * (v >> 2)) * p.ldr];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int v = half * 8 + q;
-                                crow[(size_t)((v & 3) + 8 * (v >> 2)) * p.ldc] = acc[i][j][v] + bias_r[j] + res[q];
-                            }
-                        }
-                    } else {
-                        // all 16 values first (independent polynomial chains interleave), then 16 stores
-                        float y[16];
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) {
-                            y[v] = acc[i][j][v] + bias_r[j];
-                            if constexpr (EPI == VITHIP_EPI_BIAS_GELU) y[v] = gelu_erf(y[v]);
-                        }
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) crow[(size_t)((v & 3) + 8 * (v >> 2)) * p.ldc] = y[v];
-                    }
-                }
-            }
-        }
-    } else {
-        // edge tiles (last partial M tile, N not a multiple of the tile): per-element guards
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + r;
-            const bool n_ok = n < p.N;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    if (n_ok && m < p.M) {
-                        float y = acc[i][j][v] + bias_r[j];
-                        if constexpr (AMODE == A_PATCHES) {
-                            const int im = m / p.patches, pp = m - im * p.patches;
-                            y += p.pos[(size_t)(pp + 1) * p.N + n];
-                            p.C[((size_t)m + im + 1) * p.ldc + n] = y;
-                        } else {
-                            if constexpr (EPI == VITHIP_EPI_BIAS_GELU) y = gelu_erf(y);
-                            if constexpr (EPI == VITHIP_EPI_BIAS_RESIDUAL) y += p.R[(size_t)m * p.ldr + n];
-                            p.C[(size_t)m * p.ldc + n] = y;
-                        }
-                    }
-                }
-            }
-        }
-    }
+    epilogue_store<BM, BN, WM, WN, EPI, AMODE>(p, acc, bias_r, m0, n0, wm, wn, r, h);
     if constexpr (DBG == 5) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long c3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
@@ -493,6 +342,7 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue) {
             case 103: return launch_probe<3>(stream, p);
             case 104: return launch_probe<4>(stream, p);
             case 105: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5>(stream, p) : static_cast<int>(hipErrorInvalidValue);
+            case 129: p.dbg = g_gemm_dbg; return g_gemm_dbg ? vitgemm::launch_persistent_stamped(stream, p, epilogue, g_gemm_group) : static_cast<int>(hipErrorInvalidValue);
             case 125: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5, VITHIP_EPI_BIAS, true>(stream, p) : static_cast<int>(hipErrorInvalidValue);
             case 126: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5, VITHIP_EPI_BIAS_GELU, true>(stream, p) : static_cast<int>(hipErrorInvalidValue);
             default: break;
@@ -509,6 +359,7 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue) {
         case 4: return launch_tile<128, 128, 64, 64, AMODE, 16>(stream, p, epilogue);
         case 5: return launch_tile<128, 64, 64, 32, AMODE, 16>(stream, p, epilogue);
         case 1: return launch_tile<128, 128, 64, 64, AMODE>(stream, p, epilogue);       // classic K loop
+        case 9: return vitgemm::launch_persistent(stream, p, epilogue, g_gemm_group);   // persistent, cross-tile pipelined
         case 6: return launch_tile<128, 128, 64, 64, AMODE, 16, true>(stream, p, epilogue);
         case 7: return launch_tile<256, 128, 128, 64, AMODE, 32, true>(stream, p, epilogue);
         case 8: return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
@@ -524,7 +375,7 @@ extern "C" {
 
 // Tuning hook (bench/tests): 0/1 = 128x128, 2 = 256x128, 3 = 128x64 workgroup tiles.
 int vithip_gemm_set_tile(int tile) {
-    if ((tile < 0 || tile > 8) && (tile < 101 || tile > 126)) return static_cast<int>(hipErrorInvalidValue);
+    if ((tile < 0 || tile > 9) && (tile < 101 || tile > 129)) return static_cast<int>(hipErrorInvalidValue);
     g_gemm_tile = tile;
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "vit_hip_kernels.h"
+#include "vit_gemm_common.hpp"
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -71,7 +72,58 @@ __global__ __launch_bounds__(512) void mfma_vs_valu_kernel(float *out, int iters
         if (s == 12345.678f) out[1] = s;
     }
 }
+
+// As above, but waves 4-7 evaluate GELU: mode 0 = one value at a time, 1 = eight in lock-step.
+template <int MODE>
+__global__ __launch_bounds__(512) void mfma_vs_gelu_kernel(float *out, int iters, int gelu_iters, float seed) {
+    const int wave = threadIdx.x >> 6;
+    if (wave < 4) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+        float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 1e-3f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s += acc[i][v];
+        if (s == 12345.678f) out[0] = s;
+    } else {
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = seed * (i + 1) + threadIdx.x * 1e-3f - 1.0f;
+        for (int it = 0; it < gelu_iters; ++it) {
+            if constexpr (MODE == 1) {
+                vitgemm::gelu_erf_x8(y);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = vitgemm::gelu_erf(y[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] += 0.37f;  // keep the inputs moving
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += y[i];
+        if (s == 12345.678f) out[1] = s;
+    }
+}
 }  // namespace
+
+extern "C" int vithip_probe_mfma_vs_gelu(vithip_stream_t stream, float *out, int blocks, int iters, int gelu_iters, int mode) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == 1) hipLaunchKernelGGL(mfma_vs_gelu_kernel<1>, dim3(blocks), dim3(512), 0, s, out, iters, gelu_iters, 0.37f);
+    else hipLaunchKernelGGL(mfma_vs_gelu_kernel<0>, dim3(blocks), dim3(512), 0, s, out, iters, gelu_iters, 0.37f);
+    return static_cast<int>(hipGetLastError());
+}
 
 extern "C" int vithip_probe_mfma_vs_valu(vithip_stream_t stream, float *out, int blocks, int iters, int valu_iters) {
     hipLaunchKernelGGL(mfma_vs_valu_kernel, dim3(blocks), dim3(512), 0, static_cast<hipStream_t>(stream), out, iters,

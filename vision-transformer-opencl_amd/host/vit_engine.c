@@ -22,6 +22,7 @@
 
 #include "vit_hip_kernels.h"
 
+#define VIT_MAX_LANES 4
 #define MAX_EVENTS 4096   /* stage brackets kept in flight before they are read back */
 
 struct vit_engine {
@@ -32,6 +33,8 @@ struct vit_engine {
     char err[512];
 
     vithip_stream_t stream;      /* engine-owned in-order stream */
+    vithip_stream_t aux_stream[VIT_MAX_LANES - 1]; /* extra lanes of a chunk (forward_chunk) */
+    vithip_event_t ev_fork, ev_join[VIT_MAX_LANES - 1];
     float *wblob;                /* all weights, one allocation */
     float **w;                   /* device pointer per weight index */
     int weights_loaded;
@@ -97,6 +100,7 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->device = 0;
     opt->max_batch = 256;
     opt->profile = 0;
+    opt->lanes = 1;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -146,6 +150,7 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
     e->cfg = cfg ? *cfg : vit_config_b16();
     if (opt) e->opt = *opt; else vit_engine_default_options(&e->opt);
     if (e->opt.max_batch <= 0) e->opt.max_batch = 256;
+    if (e->opt.lanes < 1) e->opt.lanes = 1;
     int rc = check_config(e);
     if (rc) return rc;
     e->tokens = vit_config_tokens(&e->cfg);
@@ -157,6 +162,11 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
         return fail(e, VIT_ERR_ARG, "device %d not available (%d HIP devices)", e->opt.device, ndev);
     HIP_TRY(e, vithip_set_device(e->opt.device));
     HIP_TRY(e, vithip_stream_create(&e->stream));
+    for (int j = 0; j < VIT_MAX_LANES - 1; ++j) {
+        HIP_TRY(e, vithip_stream_create(&e->aux_stream[j]));
+        HIP_TRY(e, vithip_event_create(&e->ev_join[j]));
+    }
+    HIP_TRY(e, vithip_event_create(&e->ev_fork));
 
     const size_t B = (size_t)e->opt.max_batch, T = (size_t)e->tokens, D = (size_t)e->cfg.embed_dim,
                  H = (size_t)e->cfg.hidden_dim, NC = (size_t)e->cfg.num_classes;
@@ -188,9 +198,21 @@ void vit_engine_destroy(vit_engine *e) {
     vithip_free(e->wblob);
     if (e->pin_in) vithip_host_free(e->pin_in);
     if (e->pin_out) vithip_host_free(e->pin_out);
+    for (int j = 0; j < VIT_MAX_LANES - 1; ++j) {
+        if (e->aux_stream[j]) { vithip_stream_sync(e->aux_stream[j]); vithip_stream_destroy(e->aux_stream[j]); }
+        if (e->ev_join[j]) vithip_event_destroy(e->ev_join[j]);
+    }
+    if (e->ev_fork) vithip_event_destroy(e->ev_fork);
     if (e->stream) vithip_stream_destroy(e->stream);
     free(e->w);
     free(e);
+}
+
+int vit_engine_set_lanes(vit_engine *e, int lanes) {
+    if (!e) return VIT_ERR_ARG;
+    if (lanes < 1 || lanes > VIT_MAX_LANES) return fail(e, VIT_ERR_ARG, "lanes must be 1..%d", VIT_MAX_LANES);
+    e->opt.lanes = lanes;
+    return VIT_OK;
 }
 
 int vit_engine_set_profile(vit_engine *e, int on) {
@@ -258,7 +280,7 @@ static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int
 
 static int collect_profile(vit_engine *e) {
     if (e->ev_used == 0) return VIT_OK;
-    HIP_TRY(e, vithip_event_sync(e->ev[2 * (e->ev_used - 1) + 1]));
+    HIP_TRY(e, vithip_device_sync()); /* brackets may sit on several lane streams */
     for (int i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
         HIP_TRY(e, vithip_event_elapsed_ms(&ms, e->ev[2 * i], e->ev[2 * i + 1]));
@@ -271,54 +293,109 @@ static int collect_profile(vit_engine *e) {
     return VIT_OK;
 }
 
-/* One chunk of nb <= max_batch images, everything device resident. */
+/*
+ * One chunk of nb <= max_batch images, everything device resident.
+ *
+ * With opt.lanes > 1 the chunk is cut into that many sub-batches that run the same stage sequence
+ * on their own HIP streams (lane 0 on the caller's stream, which forks and joins the others with
+ * events).  The sub-batches are independent -- images never interact -- so this adds no
+ * synchronisation to the data path; what it buys is that the tail of one lane's GEMM (a partial
+ * last round of tiles: 2364 tiles on 512 workgroup slots = 4.6 rounds for the N = 768 layers) and
+ * its low-occupancy kernels are filled by the other lane's workgroups instead of idling the CUs.
+ * Launches are issued stage by stage across the lanes so that the queues advance together.
+ */
+typedef struct {
+    vithip_stream_t s;
+    int off, n; /* first image of the lane inside the chunk, image count */
+} vit_lane;
+
 static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images, int nb, float *d_probs,
                          int *d_label, float *d_prob) {
     const vit_config *c = &e->cfg;
-    const int T = e->tokens, D = c->embed_dim, H = c->hidden_dim, M = nb * T;
+    const int T = e->tokens, D = c->embed_dim, H = c->hidden_dim, NC = c->num_classes;
+    const size_t img = (size_t)c->in_chans * c->img_size * c->img_size;
     float **w = e->w;
     int rc;
 
-    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_EMBED));
-    HIP_TRY(e, vithip_patch_embed_f32(s, d_images, w[1], w[2], w[0], w[3], e->x, nb, c->img_size,
-                                      c->patch_size, c->in_chans, D));
-    HIP_TRY(e, stage_end(e, s));
+    vit_lane lane[VIT_MAX_LANES];
+    int L = e->opt.lanes;
+    if (L > VIT_MAX_LANES) L = VIT_MAX_LANES;
+    if (L < 1 || nb < 2 * L) L = 1;
+    for (int j = 0; j < L; ++j) {
+        lane[j].off = (int)((long)nb * j / L);
+        lane[j].n = (int)((long)nb * (j + 1) / L) - lane[j].off;
+        lane[j].s = j == 0 ? s : e->aux_stream[j - 1];
+    }
+    if (L > 1) { /* fork: the other lanes start after everything already queued on s */
+        HIP_TRY(e, vithip_event_record(e->ev_fork, s));
+        for (int j = 1; j < L; ++j) HIP_TRY(e, vithip_stream_wait_event(lane[j].s, e->ev_fork));
+    }
 
+#define LANES for (int j = 0; j < L; ++j)
+#define ROWS(j) ((size_t)lane[j].off * T)
+    LANES {
+        HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_EMBED));
+        HIP_TRY(e, vithip_patch_embed_f32(lane[j].s, d_images + lane[j].off * img, w[1], w[2], w[0], w[3],
+                                          e->x + ROWS(j) * D, lane[j].n, c->img_size, c->patch_size, c->in_chans, D));
+        HIP_TRY(e, stage_end(e, lane[j].s));
+    }
     for (int l = 0; l < c->depth; ++l) {
         float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
-        /* LN1 (ViT_seq.c:281) */
-        HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
-        HIP_TRY(e, vithip_layernorm_f32(s, e->x, (size_t)D, e->y, (size_t)D, lw[0], lw[1], M, D));
-        HIP_TRY(e, stage_end(e, s));
-        /* QKV in_proj (ViT_seq.c:134-147) */
-        if ((rc = gemm(e, s, VIT_STAGE_QKV, e->y, D, lw[2], lw[3], NULL, e->qkv, 3 * D, M, 3 * D, D, VITHIP_EPI_BIAS))) return rc;
-        /* scores, softmax, P.V (ViT_seq.c:156-215) -> y */
-        HIP_TRY(e, stage_begin(e, s, VIT_STAGE_ATTN));
-        HIP_TRY(e, vithip_attention_f32(s, e->qkv, e->y, nb, T, c->num_heads));
-        HIP_TRY(e, stage_end(e, s));
-        /* out_proj + residual (ViT_seq.c:219-227,286-288): x = x + (y.Wo^T + bo) */
-        if ((rc = gemm(e, s, VIT_STAGE_OUTPROJ, e->y, D, lw[4], lw[5], e->x, e->x, D, M, D, D, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
-        /* LN2 (ViT_seq.c:291) */
-        HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
-        HIP_TRY(e, vithip_layernorm_f32(s, e->x, (size_t)D, e->y, (size_t)D, lw[6], lw[7], M, D));
-        HIP_TRY(e, stage_end(e, s));
-        /* fc1 + GELU (ViT_seq.c:258-264) */
-        if ((rc = gemm(e, s, VIT_STAGE_FC1, e->y, D, lw[8], lw[9], NULL, e->hbuf, H, M, H, D, VITHIP_EPI_BIAS_GELU))) return rc;
-        /* fc2 + residual (ViT_seq.c:266,297-299): x = x + (h.W2^T + b2) */
-        if ((rc = gemm(e, s, VIT_STAGE_FC2, e->hbuf, H, lw[10], lw[11], e->x, e->x, D, M, D, H, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
+        LANES { /* LN1 (ViT_seq.c:281) */
+            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+            HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D,
+                                            lw[0], lw[1], lane[j].n * T, D));
+            HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        LANES /* QKV in_proj (ViT_seq.c:134-147) */
+            if ((rc = gemm(e, lane[j].s, VIT_STAGE_QKV, e->y + ROWS(j) * D, D, lw[2], lw[3], NULL,
+                           e->qkv + ROWS(j) * 3 * D, 3 * D, lane[j].n * T, 3 * D, D, VITHIP_EPI_BIAS))) return rc;
+        LANES { /* scores, softmax, P.V (ViT_seq.c:156-215) -> y */
+            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
+            HIP_TRY(e, vithip_attention_f32(lane[j].s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, lane[j].n, T, c->num_heads));
+            HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        LANES /* out_proj + residual (ViT_seq.c:219-227,286-288): x = x + (y.Wo^T + bo) */
+            if ((rc = gemm(e, lane[j].s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, D, lw[4], lw[5], e->x + ROWS(j) * D,
+                           e->x + ROWS(j) * D, D, lane[j].n * T, D, D, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
+        LANES { /* LN2 (ViT_seq.c:291) */
+            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+            HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D,
+                                            lw[6], lw[7], lane[j].n * T, D));
+            HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        LANES /* fc1 + GELU (ViT_seq.c:258-264) */
+            if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC1, e->y + ROWS(j) * D, D, lw[8], lw[9], NULL,
+                           e->hbuf + ROWS(j) * H, H, lane[j].n * T, H, D, VITHIP_EPI_BIAS_GELU))) return rc;
+        LANES /* fc2 + residual (ViT_seq.c:266,297-299): x = x + (h.W2^T + b2) */
+            if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D,
+                           e->x + ROWS(j) * D, D, lane[j].n * T, D, H, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
     }
 
     /* final LayerNorm on the class-token rows only (ViT_seq.c:429-433 normalises all rows, uses row 0) */
     float **fw = w + 4 + VIT_WEIGHTS_PER_LAYER * c->depth;
-    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
-    HIP_TRY(e, vithip_layernorm_f32(s, e->x, (size_t)T * D, e->z, (size_t)D, fw[0], fw[1], nb, D));
-    HIP_TRY(e, stage_end(e, s));
-    /* classifier head (ViT_seq.c:435) */
-    if ((rc = gemm(e, s, VIT_STAGE_HEAD, e->z, D, fw[2], fw[3], NULL, e->logits, c->num_classes, nb, c->num_classes, D, VITHIP_EPI_BIAS))) return rc;
-    /* Softmax (ViT_seq.c:437) + top-1 (Main.c:62-70) */
-    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_SOFTMAX));
-    HIP_TRY(e, vithip_softmax_top1_f32(s, e->logits, c->num_classes, d_probs, c->num_classes, d_label, d_prob, nb, c->num_classes));
-    HIP_TRY(e, stage_end(e, s));
+    LANES {
+        HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)T * D, e->z + (size_t)lane[j].off * D,
+                                        (size_t)D, fw[0], fw[1], lane[j].n, D));
+        HIP_TRY(e, stage_end(e, lane[j].s));
+    }
+    LANES /* classifier head (ViT_seq.c:435) */
+        if ((rc = gemm(e, lane[j].s, VIT_STAGE_HEAD, e->z + (size_t)lane[j].off * D, D, fw[2], fw[3], NULL,
+                       e->logits + (size_t)lane[j].off * NC, NC, lane[j].n, NC, D, VITHIP_EPI_BIAS))) return rc;
+    LANES { /* Softmax (ViT_seq.c:437) + top-1 (Main.c:62-70) */
+        const size_t o = (size_t)lane[j].off;
+        HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_SOFTMAX));
+        HIP_TRY(e, vithip_softmax_top1_f32(lane[j].s, e->logits + o * NC, NC, d_probs + o * NC, NC,
+                                           d_label ? d_label + o : NULL, d_prob ? d_prob + o : NULL, lane[j].n, NC));
+        HIP_TRY(e, stage_end(e, lane[j].s));
+    }
+#undef LANES
+#undef ROWS
+    for (int j = 1; j < L; ++j) { /* join */
+        HIP_TRY(e, vithip_event_record(e->ev_join[j - 1], lane[j].s));
+        HIP_TRY(e, vithip_stream_wait_event(s, e->ev_join[j - 1]));
+    }
     e->last_rows = nb;
     return VIT_OK;
 }
