@@ -112,7 +112,7 @@ def main() -> None:
 
     def step():
         eng.forward_device(images.data_ptr(), B, probs.data_ptr(), top1[0].data_ptr(), top1[1].data_ptr(), sptr)
-        if world > 1:
+        if world > 1:  # the one exchange of the path: everybody receives every image's (label, prob)
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered.view(-1), top1.view(-1))
 

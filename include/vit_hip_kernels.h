@@ -95,9 +95,10 @@ typedef struct {
     int epilogue;
 } vithip_gemm_args;
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
-/* Tuning hook for benchmarks.  0 = default (128x128 tile, K step 32, software-pipelined loop);
+/* Tuning hook for benchmarks.  0 = auto (128x128 tile, K step 32: persistent walk for the bias and
+ * bias+GELU epilogues, one pipelined tile per workgroup for bias+residual);
  * classic loop: 1 = 128x128, 2 = 256x128, 3 = 128x64, 4 = 128x128 K16, 5 = 128x64 K16;
- * pipelined loop: 6 = 128x128 K16, 7 = 256x128, 8 = 128x64;
+ * pipelined loop: 10 = 128x128, 6 = 128x128 K16, 7 = 256x128, 8 = 128x64;  9 = persistent 128x128;
  * 101-105 = timing-only probe builds of the classic 128x128 kernel (wrong results by construction). */
 int vithip_gemm_set_tile(int tile);
 /* Tuning hook: tile rows per L2 group of the tile walk (default 8; 1 = plain N-fastest order). */

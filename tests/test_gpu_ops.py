@@ -62,7 +62,7 @@ def test_gemm_bias_residual(oracle):
     close(B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL), ref)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_tile_variants(oracle, tile):
     M, N, K = 515, 200, 96
     A, W, b = u(12, (M, K), 1.0), u(13, (N, K), 0.1), u(14, (N,), 0.1)

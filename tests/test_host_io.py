@@ -1,0 +1,144 @@
+"""Host side of the boundary (no GPU): loaders, 1e-6 rounding, result writer, comparator, the
+synthetic-tensor generator, and that the C-ABI library exports every symbol include/*.h declares.
+
+Reference behaviour being mirrored: Network.c:24-97,119-194 (formats + rounding),
+Main.c:62-72 (result lines), comparator.c:23-80 (label equal and |dprob| <= 0.01).
+"""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from vit_amd import binding as B
+from vit_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    L = B.lib()
+    declared = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for m in re.finditer(r"^[A-Za-z_][\w \*]*?\b(\w+)\s*\([^;{]*\)\s*;", text, flags=re.M):
+            declared.add(m.group(1))
+    assert {"ViT_hip", "ViT_opencl", "initialize_opencl", "Release_opencl", "load_weights", "load_image_data",
+            "comparator", "vithip_gemm_f32", "vit_engine_forward_device"} <= declared
+    missing = [name for name in sorted(declared) if not hasattr(L, name)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+
+
+def test_rounding_is_c_roundf_half_away_from_zero():
+    # ties at +-x.5e-6 must move away from zero (Network.c:185 uses roundf, not rint)
+    x = np.array([0.5e-6, -0.5e-6, 1.5e-6, 2.5e-6, -2.5e-6, 0.1234564, 0.1234565, 0.1234566, 3.0, -7.25], np.float32)
+    got = B.round_weights(x)
+    s = (x * np.float32(1e6)).astype(np.float64)
+    want = (np.copysign(np.floor(np.abs(s) + 0.5), s).astype(np.float32) / np.float32(1e6)).astype(np.float32)
+    assert np.array_equal(got, want)
+    big = synth.uniform(3, 1, 200000, -0.6, 0.6)
+    assert np.array_equal(B.round_weights(big), synth.round6(big))
+
+
+def test_weight_loader_layout_rounding_and_gaps(tmp_path):
+    cfg = synth.VIT_TINY
+    raw = [synth.uniform(9, i, int(np.prod(s)), -0.3, 0.3).reshape(s) for i, s in enumerate(cfg.weight_shapes())]
+    names = [f"layer_{i}_weight" for i in range(cfg.n_weights)]
+    synth.write_weight_files(str(tmp_path), raw, names)
+    os.remove(tmp_path / "Weight_6_layer_6_weight.bin")            # a missing blob stays {NULL, 0}
+    (tmp_path / "Weight_notanumber.bin").write_bytes(b"xxxx")       # no second '_': ignored
+    (tmp_path / "Weight_999_too_big.bin").write_bytes(b"\0" * 8)    # index >= count: ignored
+    (tmp_path / "Other_3_file.bin").write_bytes(b"\0" * 8)          # wrong prefix: ignored
+    (tmp_path / "Weight_2_wrong.ext").write_bytes(b"\0" * 8)        # wrong extension: ignored
+    got = B.load_weight_dir(str(tmp_path), cfg.n_weights)
+    assert got[6] is None
+    for i, w in enumerate(raw):
+        if i == 6:
+            continue
+        assert got[i].size == w.size
+        assert np.array_equal(got[i], synth.round6(w).ravel()), f"tensor {i}"
+
+
+def test_image_loader_roundtrip_and_failures(tmp_path):
+    cfg = synth.VIT_TINY
+    imgs = synth.make_images(cfg, 3, 5)
+    path = str(tmp_path / "input-3.bin")
+    synth.write_image_file(path, imgs)
+    back = B.load_image_file(path)
+    assert back.shape == imgs.shape and np.array_equal(back, imgs)
+    assert B.load_image_file(str(tmp_path / "missing.bin")) is None           # perror + NULL
+    (tmp_path / "short.bin").write_bytes(open(path, "rb").read()[:-8])
+    assert B.load_image_file(str(tmp_path / "short.bin")) is None              # short read -> NULL
+    (tmp_path / "hdr.bin").write_bytes(b"\x01\x00")
+    assert B.load_image_file(str(tmp_path / "hdr.bin")) is None
+
+
+def test_result_lines_and_reference_argmax_quirk(tmp_path):
+    probs = np.full((3, 1000), 1e-4, np.float32)
+    probs[0, 65] = 0.919345
+    probs[1, 0] = 0.5          # class 0 wins image 1 ...
+    probs[2, 230] = 0.685105
+    fixed, quirk = str(tmp_path / "fixed.txt"), str(tmp_path / "quirk.txt")
+    assert B.write_results(fixed, probs, fix_argmax=True) == 0
+    assert open(fixed).read().splitlines() == ["[0] label: 65 / prob: 0.919345", "[1] label: 0 / prob: 0.500000",
+                                               "[2] label: 230 / prob: 0.685105"]
+    # ... but Main.c:62 never resets pred_idx and the scan starts at j = 1: the reference's writer enters
+    # image 1 still pointing at class 65 and never looks at class 0 (latent bug for n > 1)
+    assert B.write_results(quirk, probs, fix_argmax=False) == 0
+    assert open(quirk).read().splitlines()[1] == "[1] label: 65 / prob: 0.000100"
+    probs[1, 0] = 1e-4
+    probs[1, 3] = 0.3
+    B.write_results(quirk, probs, fix_argmax=False)
+    assert open(quirk).read().splitlines()[1] == "[1] label: 3 / prob: 0.300000"
+
+
+def test_comparator_semantics(tmp_path):
+    ans = os.path.join(GOLD, "answer_result.txt")
+    assert B.compare_results(ans, ans, 100) == 0
+    # the reference's own committed OpenCL output differs by 0.00133 on line 0: inside the 0.01 tolerance
+    assert B.compare_results(os.path.join(GOLD, "reference_opencl_result.txt"), ans, 1) == 0
+    lines = open(ans).read().splitlines()
+    bad = list(lines)
+    bad[1] = "[1] label: 7 / prob: 0.824735"       # label mismatch          -> +1
+    bad[2] = "[2] label: 230 / prob: 0.700000"     # |dprob| = 0.0149 > 0.01 -> +1
+    bad[3] = "garbage"                              # parse error             -> +1
+    p = tmp_path / "bad.txt"
+    p.write_text("\n".join(bad) + "\n")
+    assert B.compare_results(str(p), ans, 100) == 3
+    assert B.compare_results(str(p), ans, 1) == 0                       # IMAGE_COUNT 1 (comparator.c:8)
+    assert B.compare_results(str(tmp_path / "nope.txt"), ans, 1) == 1   # unreadable file counts as one difference
+    short = tmp_path / "short.txt"
+    short.write_text("\n".join(lines[:5]) + "\n")
+    assert B.compare_results(str(short), ans, 10) == 1                  # ran out of lines
+
+
+def test_synthetic_generator_c_equals_numpy():
+    for lo, hi in ((-0.035, 0.035), (0.5, 1.0), (-2.1, 2.6)):
+        assert np.array_equal(B.synth_uniform(11, 4, 10007, lo, hi), synth.uniform(11, 4, 10007, lo, hi))
+    cfg = synth.VIT_SMALL
+    for a, b in zip(B.synth_weights_c(cfg, 21), synth.make_weights(cfg, 21, native=False)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(B.synth_images_c(cfg, 2, 9), synth.make_images(cfg, 2, 9))
+
+
+def test_model_constants():
+    L = B.lib()
+    cc = B.CConfig.of(synth.VIT_B16)
+    assert L.vit_config_macs_per_image(C.byref(cc)) == 17_563_828_224 == synth.VIT_B16.macs_per_image
+    assert synth.VIT_L16_384.macs_per_image == 191_066_300_416
+    sizes = [L.vit_config_weight_size(C.byref(cc), i) for i in range(152)]
+    assert sum(sizes) == 86_567_656                       # torchvision vit_b_16 parameter count
+    assert sizes == [int(np.prod(s)) for s in synth.VIT_B16.weight_shapes()]
+    assert L.vit_config_weight_size(C.byref(cc), 152) == 0
+    b16 = L.vit_config_b16()
+    assert (b16.img_size, b16.embed_dim, b16.depth, b16.hidden_dim) == (224, 768, 12, 3072)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(B, "_lib", None)
+    monkeypatch.setattr(B, "LIB_PATH", "/nonexistent/libvit_mi355x.so")
+    with pytest.raises(B.VitError, match="no CPU fallback"):
+        B.lib()

@@ -1,0 +1,60 @@
+"""The CPU restatement against the golden vectors the compiled reference emitted (tests/golden/).
+
+These run everywhere (the GPU box has no /root/reference): they are what pins the oracle there.
+"""
+import os
+
+import numpy as np
+
+from conftest import oracle_config
+from vit_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+T, D, H = 197, 768, 3072
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32),
+                          np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def test_ops_match_reference_vectors(oracle):
+    g = np.load(os.path.join(GOLD, "ops_b16.npz"))
+    S = int(g["seed"])
+    u = lambda k, n, a: synth.uniform(S, k, n, -a, a)  # noqa: E731  (same streams as oracle/gen_golden.py)
+    x = u(0, T * D, 2.0).reshape(T, D)
+    gam, bet = synth.uniform(S, 1, D, 0.5, 1.5), u(2, D, 0.5)
+    assert same_bits(oracle.layer_norm(x, gam, bet)[:8], g["layer_norm_rows0_8"])
+    w, bias = u(3, D * D, 0.05).reshape(D, D), u(4, D, 0.1)
+    assert same_bits(oracle.linear(x, w, bias)[:4], g["linear_rows0_4"])
+    in_w, in_b = u(5, 3 * D * D, 0.05).reshape(3 * D, D), u(6, 3 * D, 0.1)
+    xs = u(7, T * D, 1.0).reshape(T, D)
+    assert same_bits(oracle.multihead_attn(xs, in_w, in_b, w, bias, 12)[[0, 1, 100, 196]], g["mha_rows"])
+    w1, b1 = u(8, H * D, 0.05).reshape(H, D), u(9, H, 0.1)
+    w2, b2 = u(10, D * H, 0.03).reshape(D, H), u(11, D, 0.1)
+    assert same_bits(oracle.mlp_block(xs, w1, b1, w2, b2)[[0, 1, 100, 196]], g["mlp_rows"])
+    assert same_bits(oracle.softmax(u(12, 1000, 6.0)), g["softmax"])
+    assert same_bits(oracle.gelu(u(13, 4096, 4.0)), g["gelu"])
+
+
+def test_end_to_end_matches_reference_vectors(oracle):
+    g = np.load(os.path.join(GOLD, "vit_b16_e2e.npz"))
+    cfg = synth.VIT_B16
+    W = synth.make_weights(cfg, int(g["weight_seed"]))
+    imgs = synth.make_images(cfg, int(g["n_images"]), int(g["image_seed"]))
+    for i in range(imgs.shape[0]):
+        probs, logits, stages = oracle.forward_image(oracle_config(cfg), imgs[i], W, want_stages=True)
+        assert same_bits(probs, g["probs"][i])
+        assert same_bits(logits, g["logits"][i])
+        assert same_bits(stages[:, 0, :], g["stage_cls"][i][:13])
+        assert np.array_equal(stages.astype(np.float64).sum(axis=(1, 2)), g["stage_sum"][i])
+
+
+def test_reference_answer_fixture_is_well_formed():
+    """Data/answer_result.txt of the reference (100 lines `[i] label: L / prob: P`), kept as a fixture
+    for the blob-present KAT; Data/input-100.bin and 36 weight files are absent upstream."""
+    lines = open(os.path.join(GOLD, "answer_result.txt")).read().splitlines()
+    assert len(lines) == 100
+    assert lines[0] == "[0] label: 65 / prob: 0.919345"
+    for i, ln in enumerate(lines):
+        assert ln.startswith(f"[{i}] label: ")

@@ -363,7 +363,14 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue) {
         case 6: return launch_tile<128, 128, 64, 64, AMODE, 16, true>(stream, p, epilogue);
         case 7: return launch_tile<256, 128, 128, 64, AMODE, 32, true>(stream, p, epilogue);
         case 8: return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
-        default: return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);  // pipelined
+        case 10: return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);  // pipelined
+        default:
+            // auto: the persistent walk wins where the epilogue is light on registers (bias, bias+GELU:
+            // fc1 22.0 vs 23.0 ms per step); the residual epilogue needs 255 VGPRs there and is faster
+            // one tile per workgroup (fc2 21.7 vs 22.5 ms)
+            if (epilogue == VITHIP_EPI_BIAS_RESIDUAL)
+                return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
+            return vitgemm::launch_persistent(stream, p, epilogue, g_gemm_group);
     }
 }
 
@@ -375,7 +382,7 @@ extern "C" {
 
 // Tuning hook (bench/tests): 0/1 = 128x128, 2 = 256x128, 3 = 128x64 workgroup tiles.
 int vithip_gemm_set_tile(int tile) {
-    if ((tile < 0 || tile > 9) && (tile < 101 || tile > 129)) return static_cast<int>(hipErrorInvalidValue);
+    if ((tile < 0 || tile > 10) && (tile < 101 || tile > 129)) return static_cast<int>(hipErrorInvalidValue);
     g_gemm_tile = tile;
     return 0;
 }
