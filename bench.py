@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 METRIC = "images/sec ViT-B/16 224² fp32 @batch256; % MFMA roofline; top-1 match"
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it
-    "qkv": "gemm_f32_nt_kernel<EPI_BIAS>", "head": "gemm_f32_nt_kernel<EPI_BIAS>",
-    "fc1": "gemm_f32_nt_kernel<EPI_BIAS_GELU>",
+    "qkv": "gemm_f32_nt_persistent_kernel<EPI_BIAS>", "head": "gemm_f32_nt_persistent_kernel<EPI_BIAS>",
+    "fc1": "gemm_f32_nt_persistent_kernel<EPI_BIAS_GELU>",
     "outproj": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>",
     "attn": "attention_f32_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
     "softmax": "softmax_top1_f32_kernel",
@@ -57,7 +57,10 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (metric config: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
-    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per step (engine option)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="concurrent sub-batches per step (engine option; 1 = every kernel alone on the GPU)")
+    ap.add_argument("--kernel-steps", type=int, default=3,
+                    help="extra steps with lanes=1 and per-launch event brackets for the roofline object (when lanes > 1)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
     args = ap.parse_args()
 
@@ -88,7 +91,9 @@ def main() -> None:
     B = args.batch
     binding.lib().vithip_gemm_set_tile(args.gemm_tile)
     weights = synth.make_weights(cfg, 1234)
-    eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=True, lanes=args.lanes)
+    # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
+    # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
+    eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1), lanes=args.lanes)
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the
@@ -136,7 +141,21 @@ def main() -> None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    times = eng.stage_times()
+    kernel_steps = args.steps
+    if args.lanes == 1:
+        times = eng.stage_times()
+    else:
+        # kernel-level pass: same batch, same kernels, one lane, every launch bracketed by events on its stream
+        eng.set_lanes(1)
+        eng.set_profile(True)
+        step()
+        fence()
+        eng.reset_stage_times()
+        kernel_steps = max(1, args.kernel_steps)
+        for _ in range(kernel_steps):
+            step()
+        fence()
+        times = eng.stage_times()
 
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
@@ -165,7 +184,10 @@ def main() -> None:
         "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
         "whole_model_tflops": round(model_tflops, 2),
         "whole_model_frac": round(model_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-        "stage_ms_per_step": {s: round(r["ms"] / args.steps, 3) for s, r in times["stages"].items()},
+        "stage_ms_per_step": {s: round(r["ms"] / kernel_steps, 3) for s, r in times["stages"].items()},
+        "measured": ("HIP events around every launch during the timed steps" if args.lanes == 1 else
+                     f"HIP events around every launch in {kernel_steps} extra steps with lanes=1 after the timed region "
+                     f"(the timed steps run {args.lanes} concurrent lanes, whose kernels overlap)"),
     }
 
     # ---- CPU baseline + parity on the sampled image (rank 0, N = 1 only) -------------------------
@@ -194,7 +216,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "ViT-B/16 224x224 fp32 forward, batch 256 per GPU, synthetic weights and images (BASELINE.json configs[1])",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                        "gflop_per_image": round(gflop_img, 4), "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,

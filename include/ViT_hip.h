@@ -26,7 +26,7 @@
  * are processed as one batch.
  *
  * Environment: VIT_HIP_DEVICE (device ordinal, default 0), VIT_HIP_MAX_BATCH (chunk size,
- * default 256).
+ * default 256), VIT_HIP_LANES (concurrent sub-batches per chunk, default 2).
  */
 #ifndef VIT_HIP_H
 #define VIT_HIP_H

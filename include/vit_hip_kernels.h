@@ -138,6 +138,8 @@ int vithip_layernorm_f32(vithip_stream_t stream, const float *x, size_t ldx, flo
  */
 int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
                          int n_images, int tokens, int heads);
+/* Probe hook (tools/attn_probe.py): 8 x u64 cycle stamps per (image, head) workgroup; NULL disables. */
+int vithip_attention_set_debug_buffer(void *buf);
 
 /*
  * probs[r][0..classes) = softmax(logits[r]) (ViT_seq.c:304-324) and the top-1 record

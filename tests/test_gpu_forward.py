@@ -28,7 +28,7 @@ def check(probs, logits, ref_probs, ref_logits):
         assert float(np.abs(logits - ref_logits).max()) <= LOGIT_REL * scale
 
 
-@pytest.mark.parametrize("cfg,batches", [(synth.VIT_TINY, (1, 2, 5)), (synth.VIT_SMALL, (1, 3, 8))])
+@pytest.mark.parametrize("cfg,batches", [(synth.VIT_TINY, (1, 2, 5, 11)), (synth.VIT_SMALL, (1, 3, 8))])
 def test_small_models_match_live_oracle(oracle, cfg, batches):
     W = synth.make_weights(cfg, 21)
     ocfg = oracle_config(cfg)

@@ -29,10 +29,16 @@ constexpr int K_LD = HD + 4;    // padded K row (floats): conflict-free ds_read_
 constexpr int ATT_THREADS = 512;
 constexpr int ATT_WAVES = ATT_THREADS / 64;
 
+unsigned long long *g_attn_dbg = nullptr;  // see vithip_attention_set_debug_buffer()
+
 template <int NKT>  // number of 32-key tiles: tokens <= 32*NKT
 __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float *__restrict__ qkv,
                                                                     float *__restrict__ out,
-                                                                    int tokens, int heads) {
+                                                                    int tokens, int heads,
+                                                                    unsigned long long *__restrict__ dbg) {
+    // dbg != nullptr (tools/attn_probe.py --stamps): cycle stamps of wave 0 at the phase boundaries
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if (dbg) t0 = __builtin_amdgcn_s_memtime();
     constexpr int KEYS = NKT * 32;
     __shared__ __attribute__((aligned(16))) float lds[KEYS * K_LD + KEYS * HD];
     // V first: every V address is then lane_base + a 16-bit immediate (no per-key address VGPRs)
@@ -45,20 +51,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
     const float *base = qkv + (size_t)img * tokens * ld + head * HD;
 
     // ---- stage K and V of this head: 16 float4 per row, rows >= tokens are zero ----------
+    // All loads of a thread are issued before the first LDS store, so the ~100 KB of a head arrive
+    // at bandwidth rather than as NKT serial round trips.
     {
         const int c4 = (tid & 15) * 4;
-        for (int row = tid >> 4; row < KEYS; row += ATT_THREADS / 16) {
-            f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-            if (row < tokens) {
-                const float *src = base + (size_t)row * ld + c4;
-                k = *reinterpret_cast<const f32x4 *>(src + D);
-                v = *reinterpret_cast<const f32x4 *>(src + 2 * D);
-            }
-            *reinterpret_cast<f32x4 *>(Ks + row * K_LD + c4) = k;
-            *reinterpret_cast<f32x4 *>(Vs + row * HD + c4) = v;
+        constexpr int ROWS_PER_PASS = ATT_THREADS / 16;  // 32
+        f32x4 kreg[NKT], vreg[NKT];
+#pragma unroll
+        for (int it = 0; it < NKT; ++it) {
+            const int row = (tid >> 4) + it * ROWS_PER_PASS;
+            const int srow = row < tokens ? row : tokens - 1;  // clamped address, value discarded below
+            const float *src = base + (size_t)srow * ld + c4;
+            kreg[it] = *reinterpret_cast<const f32x4 *>(src + D);
+            vreg[it] = *reinterpret_cast<const f32x4 *>(src + 2 * D);
+        }
+#pragma unroll
+        for (int it = 0; it < NKT; ++it) {
+            const int row = (tid >> 4) + it * ROWS_PER_PASS;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(Ks + row * K_LD + c4) = row < tokens ? kreg[it] : zero;
+            *reinterpret_cast<f32x4 *>(Vs + row * HD + c4) = row < tokens ? vreg[it] : zero;
         }
     }
     __syncthreads();
+    if (dbg) t1 = __builtin_amdgcn_s_memtime();
 
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -79,24 +95,35 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
         }
 
         // ---- S^T = K . Q^T -----------------------------------------------------------
+        // K fragments are double-buffered in registers: the 8 ds_read_b128 of tile kt+1 are issued before
+        // the 32 MFMAs of tile kt, so their LDS latency never stalls the matrix pipe.
         f32x16 st[NKT];
+        f32x4 kf[2][8];
+        auto read_k = [&](int kt, int set) {
+            const float *kp = Ks + (kt * 32 + r) * K_LD + h * 4;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kf[set][c] = *reinterpret_cast<const f32x4 *>(kp + c * 8);
+        };
+        read_k(0, 0);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) st[kt][v] = 0.0f;
-            const float *kp = Ks + (kt * 32 + r) * K_LD + h * 4;
+            if (kt + 1 < NKT) read_k(kt + 1, (kt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const f32x4 kf = *reinterpret_cast<const f32x4 *>(kp + c * 8);
+            for (int c = 0; c < 8; ++c)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[c][s], st[kt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the next tile's K reads from piling up in VGPRs
+                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kt & 1][c][s], qf[c][s], st[kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- row softmax over keys (ViT_seq.c:174-191) --------------------------------
+        if (dbg) t2 = __builtin_amdgcn_s_memtime();
         // Only the last key tile can hold keys >= tokens (NKT = ceil(tokens/32)).
+        // fp32 VALU work is paid for in matrix-pipe time on gfx950 (it shares the lanes of
+        // v_mfma_f32_32x32x2_f32), so the softmax is kept to 4 instructions per score:
+        // max, then p = exp2(s*c - m*c) as one fma + v_exp_f32 with c = log2(e)/sqrtf(64), then add.
         float mx = -INFINITY;
         const int rem = tokens - (NKT - 1) * 32;  // valid keys in the last tile, 1..32
         const int h4 = 4 * h;
@@ -104,52 +131,67 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                float s = st[kt][v] * 0.125f;  // / sqrtf(64), exact
                 if (kt == NKT - 1) {
                     const int kloc = (v & 3) + 8 * (v >> 2);  // + 4h = key index inside the tile
-                    s = h4 < rem - kloc ? s : -INFINITY;
+                    st[kt][v] = h4 < rem - kloc ? st[kt][v] : -INFINITY;
                 }
-                st[kt][v] = s;
-                mx = fmaxf(mx, s);
+                mx = fmaxf(mx, st[kt][v]);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        constexpr float kScale = 0.125f * 1.4426950408889634f;  // (1/sqrtf(64)) * log2(e)
+        const float mxs = -mx * kScale;
         float sum = 0.0f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const float e = expf(st[kt][v] - mx);  // exp(-inf) = 0 for masked keys
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));  // exp2(-inf) = 0: masked keys
                 st[kt][v] = e;
                 sum += e;
-                if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
 
+        if (dbg) t3 = __builtin_amdgcn_s_memtime();
         // ---- O^T = V^T . P^T -----------------------------------------------------------
+        // Groups of 4 accumulator registers = 4 consecutive keys per lane half (8 MFMAs, 8 ds_read_b32);
+        // the V values of group g+1 are fetched before the MFMAs of group g.  Tiles before the last are
+        // full; in the last tile a group is skipped when its first key is past the end (wave-uniform).
         f32x16 o[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int v = 0; v < 16; ++v) o[dt][v] = 0.0f;
+        constexpr int NG = NKT * 4;
+        float va[2][8];
+        const float *vbase = Vs + 4 * h * HD + r;
+        auto read_v = [&](int g, int set) {
+            const int key0 = (g >> 2) * 32 + 8 * (g & 3);  // key of register 4*(g&3) on lanes 0-31
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int key_a = kt * 32 + (v & 3) + 8 * (v >> 2);  // lanes 0-31; lanes 32-63: +4
-                // tiles before the last are full (NKT = ceil(tokens/32)); the test is wave-uniform
-                if (kt < NKT - 1 || key_a < tokens) {
-                    const float *vp = Vs + (key_a + 4 * h) * HD + r;
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], st[kt][v], o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], st[kt][v], o[1], 0, 0, 0);
-                }
-                if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) {
+                va[set][2 * q] = vbase[(key0 + q) * HD];
+                va[set][2 * q + 1] = vbase[(key0 + q) * HD + 32];
             }
+        };
+        read_v(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int kt = g >> 2, v0 = 4 * (g & 3);
+            if (g + 1 < NG) read_v(g + 1, (g + 1) & 1);  // rows past `tokens` are zero-filled, always readable
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt < NKT - 1 || kt * 32 + 8 * (g & 3) < tokens) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g & 1][2 * q], st[kt][v0 + q], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g & 1][2 * q + 1], st[kt][v0 + q], o[1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
+        if (dbg) t4 = __builtin_amdgcn_s_memtime();
         // ---- store: lane owns query q0+r; registers 4g..4g+3 are 4 consecutive d ---------
         if (q0 + r < tokens) {
             float *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
@@ -166,16 +208,27 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
                 }
         }
     }
+    if (dbg && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long *d = dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = t4; d[5] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 template <int NKT>
 int launch(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads) {
     hipLaunchKernelGGL(attention_f32_kernel<NKT>, dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out,
-                       tokens, heads);
+                       tokens, heads, g_attn_dbg);
     return static_cast<int>(hipGetLastError());
 }
 
 }  // namespace
+
+// Probe hook: 8 x u64 cycle stamps per (image, head) workgroup; nullptr (default) disables them.
+extern "C" int vithip_attention_set_debug_buffer(void *buf) {
+    g_attn_dbg = static_cast<unsigned long long *>(buf);
+    return 0;
+}
 
 extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
                                     int n_images, int tokens, int heads) {

