@@ -131,10 +131,11 @@ int vithip_layernorm_f32(vithip_stream_t stream, const float *x, size_t ldx, flo
                          const float *gamma, const float *beta, int rows, int dim);
 
 /*
- * Fused scaled-dot-product attention, one workgroup per (image, head).
+ * Fused scaled-dot-product attention, one workgroup per (image, head) (x blocks of 256 queries when chunked).
  * qkv: [n*T][3*D] rows = tokens, columns [Q | K | V], head h = columns 64h..64h+63 of each.
  * out: [n*T][D].  scores = q.k / sqrtf(64); row softmax with max subtraction; out = P.V.
- * head_dim must be 64; tokens <= 224 (K and V of one head stay resident in LDS).
+ * head_dim must be 64.  Up to 224 tokens K and V of one head stay resident in LDS; longer sequences
+ * (ViT-L/16-384: 577) stream K/V through LDS in 224-key chunks with an online softmax.
  */
 int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
                          int n_images, int tokens, int heads);

@@ -36,7 +36,7 @@ typedef struct {
  * Model dimensions.  The reference fixes them with macros (ViT_seq.c:10-21,
  * ViT_opencl.c:12-23); here they are a runtime struct so that the same engine serves
  * ViT-B/16-224 (the default), reduced test models and ViT-L/16-384.
- * Constraints of the HIP path: embed_dim / num_heads == 64, embed_dim % 32 == 0,
+ * Constraints of the HIP path: embed_dim / num_heads == 64, embed_dim % 32 == 0, embed_dim <= 2048,
  * hidden_dim % 32 == 0, patch_size % 4 == 0, in_chans*patch_size^2 % 32 == 0.
  */
 typedef struct {

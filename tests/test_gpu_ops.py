@@ -125,10 +125,29 @@ def test_attention_peaked_rows(oracle):
     assert float(np.abs(got - ref).max()) <= 2e-4 * float(np.abs(ref).max())
 
 
-def test_attention_rejects_long_sequences():
-    qkv = np.zeros((225, 192), np.float32)
-    with pytest.raises(B.VitError):
-        B.attention(qkv, 1, 225, 1)
+@pytest.mark.parametrize("n,T,heads", [(1, 225, 1), (2, 300, 2), (1, 448, 1), (2, 577, 2), (1, 700, 1)])
+def test_attention_long_sequences_chunked(oracle, n, T, heads):
+    """More than 224 tokens: K/V stream through LDS in chunks with an online softmax (ViT-L/16-384: 577)."""
+    D = heads * 64
+    qkv = u(32, (n * T, 3 * D), 2.5)
+    got = B.attention(qkv, n, T, heads).reshape(n, T, D)
+    for i in range(n):
+        blk = qkv[i * T:(i + 1) * T]
+        q, k, v = (np.ascontiguousarray(blk[:, j * D:(j + 1) * D]) for j in range(3))
+        ref = oracle.attention_core(q, k, v, heads)
+        err = float(np.abs(got[i] - ref).max())
+        assert err <= 2e-5 * max(1.0, float(np.abs(ref).max())), f"image {i}: {err}"
+
+
+def test_attention_chunked_running_max_moves(oracle):
+    """Force the rescale branch: the row maximum sits in the LAST chunk for half of the queries."""
+    T, heads = 500, 1
+    qkv = u(33, (T, 192), 1.0)
+    qkv[450:, 64:128] *= 6.0  # large keys at the end of the sequence
+    got = B.attention(qkv, 1, T, heads)
+    q, k, v = (np.ascontiguousarray(qkv[:, j * 64:(j + 1) * 64]) for j in range(3))
+    ref = oracle.attention_core(q, k, v, heads)
+    assert float(np.abs(got - ref).max()) <= 2e-5 * float(np.abs(ref).max())
 
 
 # ---- patch embedding ------------------------------------------------------------------------------

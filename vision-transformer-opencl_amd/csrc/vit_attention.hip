@@ -215,6 +215,167 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Any sequence length: K/V of the head stream through LDS in chunks of 224 keys with an online softmax
+// (running row maximum m, running sum l, O rescaled by exp2((m_old - m_new) c) when the maximum moves).
+// Needed once K and V of one head no longer fit the 160 KB LDS: ViT-L/16-384 has 577 tokens
+// (2 x 577 x 64 fp32 = 295 KB).  Same fragment scheme as the resident kernel above; grid =
+// (heads, images, blocks of 8 query tiles).
+constexpr int CKT = 7;           // key tiles per chunk
+constexpr int CKEYS = CKT * 32;  // 224 keys per chunk
+
+__global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(const float *__restrict__ qkv,
+                                                                            float *__restrict__ out, int tokens,
+                                                                            int heads) {
+    __shared__ __attribute__((aligned(16))) float lds[CKEYS * K_LD + CKEYS * HD];
+    float *const Vs = lds;
+    float *const Ks = lds + CKEYS * HD;
+
+    const int head = blockIdx.x, img = blockIdx.y;
+    const int D = heads * HD, ld = 3 * D;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const float *base = qkv + (size_t)img * tokens * ld + head * HD;
+
+    const int q0 = (blockIdx.z * ATT_WAVES + wave) * 32;
+    const bool active = q0 < tokens;  // wave-uniform
+
+    f32x4 qf[8];
+    {
+        int qrow = q0 + r;
+        qrow = qrow < tokens ? qrow : tokens - 1;
+        const float *qsrc = base + (size_t)qrow * ld + h * 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4 *>(qsrc + c * 8);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[dt][v] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;  // l_run: this lane half's share of the row sum
+    constexpr float kScale = 0.125f * 1.4426950408889634f;
+    const int h4 = 4 * h;
+
+    const int nchunks = (tokens + CKEYS - 1) / CKEYS;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int key_base = ch * CKEYS;
+        const int ckeys = tokens - key_base < CKEYS ? tokens - key_base : CKEYS;  // valid keys in this chunk
+        if (ch > 0) __syncthreads();  // everybody is done reading the previous chunk
+        {
+            const int c4 = (tid & 15) * 4;
+            constexpr int ROWS_PER_PASS = ATT_THREADS / 16;
+            f32x4 kreg[CKT], vreg[CKT];
+#pragma unroll
+            for (int it = 0; it < CKT; ++it) {
+                const int row = (tid >> 4) + it * ROWS_PER_PASS;
+                const int srow = key_base + (row < ckeys ? row : ckeys - 1);
+                const float *src = base + (size_t)srow * ld + c4;
+                kreg[it] = *reinterpret_cast<const f32x4 *>(src + D);
+                vreg[it] = *reinterpret_cast<const f32x4 *>(src + 2 * D);
+            }
+#pragma unroll
+            for (int it = 0; it < CKT; ++it) {
+                const int row = (tid >> 4) + it * ROWS_PER_PASS;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(Ks + row * K_LD + c4) = row < ckeys ? kreg[it] : zero;
+                *reinterpret_cast<f32x4 *>(Vs + row * HD + c4) = row < ckeys ? vreg[it] : zero;
+            }
+        }
+        __syncthreads();
+        if (!active) continue;  // wave-uniform; the barriers above are still reached by every wave
+
+        // ---- S^T = K . Q^T for the chunk; tiles past the end are skipped (and masked below) ------
+        f32x16 st[CKT];
+#pragma unroll
+        for (int kt = 0; kt < CKT; ++kt) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) st[kt][v] = 0.0f;
+            if (kt * 32 < ckeys) {
+                const float *kp = Ks + (kt * 32 + r) * K_LD + h * 4;
+                f32x4 kf[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) kf[c] = *reinterpret_cast<const f32x4 *>(kp + c * 8);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+                        st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c][s2], qf[c][s2], st[kt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- online softmax -------------------------------------------------------------------------
+        float cmax = -INFINITY;
+        if (ckeys < CKEYS) {  // only the last chunk can be ragged
+#pragma unroll
+            for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int kloc = kt * 32 + (v & 3) + 8 * (v >> 2);
+                    st[kt][v] = h4 < ckeys - kloc ? st[kt][v] : -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, st[kt][v]);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);                                   // finite: every chunk has a key
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kScale);     // first chunk: exp2(-inf) = 0
+        m_run = m_new;
+        const float mxs = -m_new * kScale;
+        float csum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
+                st[kt][v] = e;
+                csum += e;
+            }
+        l_run = l_run * alpha + csum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[dt][v] *= alpha;
+
+        // ---- O^T += V^T . P^T -----------------------------------------------------------------------
+        const float *vbase = Vs + 4 * h * HD + r;
+#pragma unroll
+        for (int g = 0; g < CKT * 4; ++g) {
+            const int kt = g >> 2, v0 = 4 * (g & 3);
+            const int key0 = kt * 32 + 8 * (g & 3);
+            if (key0 < ckeys) {  // wave-uniform; rows past the end are zero-filled and their P is 0
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vbase[(key0 + q) * HD], st[kt][v0 + q], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vbase[(key0 + q) * HD + 32], st[kt][v0 + q], o[1], 0, 0, 0);
+                }
+            }
+            if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    if (active && q0 + r < tokens) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / l_tot;
+        float *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w;
+                w[0] = o[dt][4 * g + 0] * inv;
+                w[1] = o[dt][4 * g + 1] * inv;
+                w[2] = o[dt][4 * g + 2] * inv;
+                w[3] = o[dt][4 * g + 3] * inv;
+                *reinterpret_cast<f32x4 *>(dst + dt * 32 + 8 * g) = w;
+            }
+    }
+}
+
 template <int NKT>
 int launch(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads) {
     hipLaunchKernelGGL(attention_f32_kernel<NKT>, dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out,
@@ -245,6 +406,11 @@ extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, fl
         case 5: return launch<5>(s, qkv, out, n_images, tokens, heads);
         case 6: return launch<6>(s, qkv, out, n_images, tokens, heads);
         case 7: return launch<7>(s, qkv, out, n_images, tokens, heads);
-        default: return static_cast<int>(hipErrorInvalidValue);  // > 224 tokens: K/V tiling not built yet
+        default: {  // > 224 tokens: K/V stream through LDS in chunks, online softmax
+            const int qblocks = (nkt + ATT_WAVES - 1) / ATT_WAVES;
+            hipLaunchKernelGGL(attention_f32_chunked_kernel, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s,
+                               qkv, out, tokens, heads);
+            return static_cast<int>(hipGetLastError());
+        }
     }
 }

@@ -136,8 +136,6 @@ static int check_config(vit_engine *e) {
         return fail(e, VIT_ERR_ARG, "embed_dim and hidden_dim must be multiples of 32");
     if (c->patch_size % 4 || c->img_size % 4 || (c->in_chans * c->patch_size * c->patch_size) % 32)
         return fail(e, VIT_ERR_ARG, "patch geometry unsupported (patch%%4, img%%4, C*P*P%%32 must be 0)");
-    if (vit_config_tokens(c) > 224)
-        return fail(e, VIT_ERR_ARG, "more than 224 tokens (%d): K/V-tiled attention is not built yet", vit_config_tokens(c));
     if (c->embed_dim > 2048) return fail(e, VIT_ERR_ARG, "embed_dim > 2048 unsupported by the LayerNorm kernel");
     return VIT_OK;
 }
