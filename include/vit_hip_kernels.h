@@ -104,6 +104,23 @@ int vithip_gemm_set_tile(int tile);
 /* Tuning hook: tile rows per L2 group of the tile walk (default 8; 1 = plain N-fastest order). */
 int vithip_gemm_set_group(int group_m);
 
+/* ---- bf16 variant (BASELINE.json configs[2]) ---------------------------------
+ * bf16 values are raw uint16 (upper half of the fp32 bit pattern, round-to-nearest-even). */
+enum { VITHIP_BF16_EPI_BF16 = 0, VITHIP_BF16_EPI_BF16_GELU = 1, VITHIP_BF16_EPI_F32_RESIDUAL = 2 };
+typedef struct {
+    const unsigned short *A; int lda;   /* bf16 [M][lda], K contiguous */
+    const unsigned short *W; int ldw;   /* bf16 [N][ldw] */
+    const float *bias;                  /* fp32 [N] */
+    const float *residual; int ldr;     /* fp32, EPI_F32_RESIDUAL only; may alias C */
+    void *C; int ldc;                   /* bf16 (EPI_BF16, EPI_BF16_GELU) or fp32 (EPI_F32_RESIDUAL) */
+    int M, N, K;                        /* K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0 */
+    int epilogue;
+} vithip_gemm_bf16_args;
+/* C = epilogue(A . W^T + bias) on v_mfma_f32_32x32x16_bf16, fp32 accumulate. */
+int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
+/* dst[i] = bf16(src[i]), round to nearest even; count % 4 == 0. */
+int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short *dst, size_t count);
+
 /* Measurement probe: register-only fp32 MFMA loop; each wave issues iters*32 v_mfma_f32_32x32x2_f32
  * (4096 flop each).  Used by tools/gemm_probe.py to read the sustained matrix clock. */
 int vithip_probe_mfma_f32(vithip_stream_t stream, float *out, int blocks, int threads, int iters);

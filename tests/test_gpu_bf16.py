@@ -1,0 +1,53 @@
+"""bf16 variant (BASELINE.json configs[2]): op-level checks of the bf16 MFMA GEMM.
+
+Inputs are rounded to bf16 on the host first, so the oracle (fp32 arithmetic on the SAME values) differs
+from the kernel only by fp32 accumulation order; bf16 outputs are additionally rounded once
+(relative 2^-8).  Tolerances are written where they are used.
+"""
+import numpy as np
+import pytest
+
+from vit_amd import binding as B
+from vit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def u(k, shape, a, seed=999):
+    return synth.uniform(seed, k, int(np.prod(shape)), -a, a).reshape(shape)
+
+
+def test_f32_to_bf16_matches_round_to_nearest_even():
+    x = np.concatenate([u(0, (4096,), 3.0), np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 65504.0, 1e-30, -1e30], np.float32)])
+    x = x[: (x.size // 4) * 4]
+    assert np.array_equal(B.f32_to_bf16_device(x), B.to_bf16_bits(x))
+
+
+def test_gemm_bf16_identity_asymmetric_exact():
+    K = 256
+    A = B.to_bf16_bits(np.eye(K, dtype=np.float32))
+    Wf = B.from_bf16_bits(B.to_bf16_bits(u(1, (256, K), 1.0)))      # values exactly representable in bf16
+    got = B.gemm_bf16(A, B.to_bf16_bits(Wf), np.zeros(256, np.float32), residual=np.zeros((K, 256), np.float32),
+                      epilogue=B.BF16_EPI_F32_RESIDUAL)
+    assert np.array_equal(got, Wf.T.copy())
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (197, 2304, 768), (300, 100, 64), (1000, 768, 3072), (5, 12, 128)])
+def test_gemm_bf16_residual_fp32_out(oracle, M, N, K):
+    Ab, Wb = B.to_bf16_bits(u(2, (M, K), 1.0)), B.to_bf16_bits(u(3, (N, K), 0.05))
+    b, R = u(4, (N,), 0.1), u(5, (M, N), 2.0)
+    ref = R + oracle.linear(B.from_bf16_bits(Ab), B.from_bf16_bits(Wb), b)
+    got = B.gemm_bf16(Ab, Wb, b, residual=R, epilogue=B.BF16_EPI_F32_RESIDUAL)
+    assert float(np.abs(got - ref).max()) <= 2e-5 * float(np.abs(ref).max())   # fp32 accumulation order only
+
+
+@pytest.mark.parametrize("epi", [B.BF16_EPI_BF16, B.BF16_EPI_BF16_GELU])
+def test_gemm_bf16_bf16_out(oracle, epi):
+    M, N, K = 515, 3072, 768
+    Ab, Wb, b = B.to_bf16_bits(u(6, (M, K), 1.0)), B.to_bf16_bits(u(7, (N, K), 0.08)), u(8, (N,), 0.1)
+    ref = oracle.linear(B.from_bf16_bits(Ab), B.from_bf16_bits(Wb), b)
+    if epi == B.BF16_EPI_BF16_GELU:
+        ref = oracle.gelu(ref)
+    got = B.from_bf16_bits(B.gemm_bf16(Ab, Wb, b, epilogue=epi))
+    err = np.abs(got - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), float(err.max())       # one bf16 rounding of the result

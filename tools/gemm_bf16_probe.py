@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Time the bf16 MFMA GEMM at the batch-2048 ViT-B/16 shapes (GPU box only)."""
+import ctypes as C, importlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+B = importlib.import_module("vision-transformer-opencl_amd.binding")
+from tools.gemm_probe import timed
+L = B.lib()
+L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(B.CGemmBf16Args)]
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+M = batch * 197
+SHAPES = {"qkv": (M, 2304, 768, 0), "outproj": (M, 768, 768, 2), "fc1": (M, 3072, 768, 1), "fc2": (M, 768, 3072, 2)}
+rng = np.random.default_rng(0)
+for name, (M_, N, K, epi) in SHAPES.items():
+    a = rng.integers(0x3c00, 0x4000, size=(M_, K), dtype=np.uint16)  # bf16 bit patterns in [0.0078, 2)
+    a[::2] |= 0x8000                                                 # mixed signs
+    dA = B.DeviceArray.from_numpy(a)
+    dW = B.DeviceArray.from_numpy(B.to_bf16_bits(rng.uniform(-.05, .05, (N, K)).astype(np.float32)))
+    db = B.DeviceArray.from_numpy(rng.uniform(-.1, .1, (N,)).astype(np.float32))
+    out_f32 = epi == 2
+    dC = B.DeviceArray((M_, N), np.float32 if out_f32 else np.uint16)
+    args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if out_f32 else None, N, dC.ptr, N, M_, N, K, epi)
+    ms = [timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=3, warm=1) for _ in range(3)]
+    print(json.dumps({name: {"ms": [round(m, 3) for m in ms], "tflops": round(2.0 * M_ * N * K / (min(ms) * 1e-3) / 1e12, 1)}}))
+    for d in (dA, dW, db, dC):
+        d.free()

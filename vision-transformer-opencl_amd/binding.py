@@ -213,6 +213,52 @@ def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS) -> np.ndarray:
     return dC.numpy()
 
 
+class CGemmBf16Args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int), ("bias", C.c_void_p),
+                ("residual", C.c_void_p), ("ldr", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int)]
+
+
+BF16_EPI_BF16, BF16_EPI_BF16_GELU, BF16_EPI_F32_RESIDUAL = 0, 1, 2
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit patterns (uint16), round to nearest even (host model of v_cvt_pk_bf16_f32)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def f32_to_bf16_device(x: np.ndarray) -> np.ndarray:
+    """The device conversion kernel (vithip_f32_to_bf16)."""
+    x = _as_f32(x)
+    L = lib()
+    L.vithip_f32_to_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    dx = DeviceArray.from_numpy(x)
+    dy = DeviceArray(x.shape, np.uint16)
+    hip_check(L.vithip_f32_to_bf16(None, dx.ptr, dy.ptr, x.size), "vithip_f32_to_bf16")
+    return dy.numpy()
+
+
+def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16) -> np.ndarray:
+    """vithip_gemm_bf16 on bf16 bit patterns; returns bf16 bits (uint16) or fp32 for the residual epilogue."""
+    L = lib()
+    L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(CGemmBf16Args)]
+    M, K = A_bits.shape
+    N = W_bits.shape[0]
+    dA, dW = DeviceArray.from_numpy(np.ascontiguousarray(A_bits, np.uint16)), DeviceArray.from_numpy(np.ascontiguousarray(W_bits, np.uint16))
+    db = DeviceArray.from_numpy(_as_f32(bias))
+    out_f32 = epilogue == BF16_EPI_F32_RESIDUAL
+    dC = DeviceArray((M, N), np.float32 if out_f32 else np.uint16)
+    dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
+    args = CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue)
+    hip_check(L.vithip_gemm_bf16(None, C.byref(args)), "vithip_gemm_bf16")
+    return dC.numpy()
+
+
 def layernorm(x, gamma, beta) -> np.ndarray:
     x = _as_f32(x)
     rows, dim = x.shape

@@ -1,0 +1,278 @@
+// csrc/vit_gemm_bf16.hip -- bf16 MFMA "NT" GEMM (fp32 accumulate) for the bf16 variant of the forward
+// (BASELINE.json configs[2]: ViT-B/16, batch 2048, bf16 MFMA).
+//
+//   C = epilogue(A[M][K] . W[N][K]^T + bias),  A and W bf16 (K contiguous), bias fp32, accumulate fp32.
+//   epilogues:  BF16       C bf16 = acc + bias                      (QKV in_proj)
+//               BF16_GELU  C bf16 = gelu_erf(acc + bias)            (fc1; ViT_seq.c:231-233)
+//               F32_RES    C fp32 = acc + bias + R fp32, R may be C (out_proj, fc2: the residual stream
+//                                                                    stays fp32, ViT_seq.c:286-288,297-299)
+//
+// Design (gfx950, after the measurements of the CDNA4 guide: 256x256 tile, direct-to-LDS loads, XOR swizzle):
+//  * v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16 block, 16x the fp32 MFMA rate, so operand delivery
+//    decides everything.  Workgroup = 8 waves (2 per SIMD), tile 256x256, K step 64 (128-B rows in LDS);
+//    a wave owns 128(m) x 64(n): 4x2 accumulators, 6 ds_read_b128 per 8 MFMAs.  HBM/L2 -> LDS traffic is
+//    64 KB per 2048 matrix-pipe cycles = 32 B/clk/CU.
+//  * global_load_lds_dwordx4 (LDS-DMA, 16 B per lane): no staging registers and no ds_write; each wave
+//    instruction fills 8 rows x 128 B.  The LDS image is lane-linear, so the bank-conflict swizzle
+//    (16-B chunk c of row r lives at chunk c ^ ((r >> 1) & 7)) is applied to the per-lane SOURCE address
+//    and again on the ds_read side.  Two LDS stages; the loads of step t+1 are issued before the MFMAs
+//    of step t and drained (vmcnt(0)) at the single barrier that ends the step.
+//  * Operand roles are swapped (MFMA A = W rows, B = activation rows): a lane then owns ONE output row m
+//    and 4 consecutive columns n per register group, so the epilogue packs 4 bf16 (8 B) or one float4 per
+//    store instead of scattering 2-byte elements.
+//  * Tile walk: XCD-aware remap + groups of 8 tile rows (as the fp32 kernel).
+#include "vit_gemm_common.hpp"
+
+namespace {
+
+using vitgemm::erf_fp32;
+using vitgemm::tile_coords;
+using vitgemm::xcd_remap;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+constexpr int TBM = 256, TBN = 256, TBK = 64;      // bf16 elements
+constexpr int ROWB = TBK * 2;                      // 128 bytes per LDS row
+constexpr int STAGE_BYTES = (TBM + TBN) * ROWB;    // 64 KB
+constexpr int THREADS = 512;
+
+struct Bf16Params {
+    const bf16_t *A;
+    const bf16_t *W;
+    const float *bias;
+    const float *R;
+    void *C;
+    int lda, ldw, ldr, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n, group_m;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <int EPI>
+__global__ __launch_bounds__(THREADS, 2) void gemm_bf16_nt_kernel(const Bf16Params p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 128 rows x 64 columns each
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+
+    // ---- staging: wave w fills rows [32w, 32w+32) of the A tile and of the W tile, 4 DMA instructions
+    // each (8 rows x 128 B per instruction).  Lane l lands at (row q*8 + l/8, chunk l%8) and therefore
+    // fetches source chunk (l%8) ^ ((row>>1)&7) of that row.
+    const char *a_src[4];
+    const char *w_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 32 + q * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        a_src[q] = reinterpret_cast<const char *>(p.A + (size_t)m * p.lda) + chunk * 16;
+        w_src[q] = reinterpret_cast<const char *>(p.W + (size_t)n * p.ldw) + chunk * 16;
+    }
+    auto stage = [&](int buf, int k0) {
+        char *a_dst = lds + buf * STAGE_BYTES + wave * 32 * ROWB;
+        char *w_dst = a_dst + TBM * ROWB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(a_src[q] + (size_t)k0 * 2), (lds_void *)(a_dst + q * 8 * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(w_src[q] + (size_t)k0 * 2), (lds_void *)(w_dst + q * 8 * ROWB), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses: row (wave tile row + r), logical 16-B chunk 2*ks + h, swizzled ------
+    int a_off[4], w_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm * 128 + i * 32 + r;
+        a_off[i] = row * ROWB;  // + ((2*ks + h) ^ sw) * 16 per k16 step, sw below
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + r;
+        w_off[j] = TBM * ROWB + row * ROWB;
+    }
+    const int sw = (r >> 1) & 7;  // every fragment row of this lane is r (mod 32): same swizzle key
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
+
+    const int nk = p.K / TBK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * TBK);
+        const char *base = lds + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            const int coff = (((2 * ks + h) ^ sw) & 7) * 16;
+            bf16x8 wf[2], af[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(base + w_off[j] + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(base + a_off[i] + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of the next stage has landed
+        __syncthreads();                                    // ... and everybody is done reading this one
+    }
+
+    // ---- epilogue: lane owns row m, register group g of accumulator (j, i) = columns nb .. nb+3 ------
+    // vmcnt counts stores: a load waited for between stores serialises them on the write latency (the
+    // lesson of the fp32 kernel).  So all 8 bias vectors are fetched up front, interior tiles run without
+    // a single branch, and residual rows are fetched four at a time before their four stores.
+    f32x4 b4[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+            nb = nb + 4 <= p.N ? nb : p.N - 4;  // clamped address; such groups are never stored
+            b4[j][g] = *reinterpret_cast<const f32x4 *>(p.bias + nb);
+        }
+    auto finish = [&](float t) {
+        if constexpr (EPI == VITHIP_BF16_EPI_BF16_GELU) t = 0.5f * t * (1.0f + erf_fp32(t * 0.70710678118654752440f));
+        return t;
+    };
+    const bool interior = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);  // workgroup-uniform
+    if (interior) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+                const size_t mrow = (size_t)(m0 + wm * 128 + r);
+                if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
+                    f32x4 res[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[i] = *reinterpret_cast<const f32x4 *>(p.R + (mrow + i * 32) * p.ldr + nb);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 y;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y[q] = acc[j][i][4 * g + q] + b4[j][g][q] + res[i][q];
+                        *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + (mrow + i * 32) * p.ldc + nb) = y;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        bf16x4 y;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y[q] = (__bf16)finish(acc[j][i][4 * g + q] + b4[j][g][q]);
+                        *reinterpret_cast<bf16x4 *>(static_cast<bf16_t *>(p.C) + (mrow + i * 32) * p.ldc + nb) = y;
+                    }
+                }
+            }
+    } else {
+        // edge tiles: per-row / per-group guards
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + wm * 128 + i * 32 + r;
+                    if (m < p.M && nb + 4 <= p.N) {
+                        if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
+                            const f32x4 res = *reinterpret_cast<const f32x4 *>(p.R + (size_t)m * p.ldr + nb);
+                            f32x4 y;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y[q] = acc[j][i][4 * g + q] + b4[j][g][q] + res[q];
+                            *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + (size_t)m * p.ldc + nb) = y;
+                        } else {
+                            bf16x4 y;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y[q] = (__bf16)finish(acc[j][i][4 * g + q] + b4[j][g][q]);
+                            *reinterpret_cast<bf16x4 *>(static_cast<bf16_t *>(p.C) + (size_t)m * p.ldc + nb) = y;
+                        }
+                    }
+                }
+            }
+    }
+}
+
+// fp32 -> bf16 (round to nearest even; NaN stays NaN through v_cvt_pk_bf16_f32), 4 elements per thread.
+__global__ void f32_to_bf16_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(src)[i];
+        bf16x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (__bf16)v[q];
+        reinterpret_cast<bf16x4 *>(dst)[i] = o;
+    }
+}
+
+bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short *dst, size_t count) {
+    if (!src || !dst || count % 4 || !aligned16(src) || (reinterpret_cast<size_t>(dst) & 7))
+        return static_cast<int>(hipErrorInvalidValue);
+    if (count == 0) return 0;
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, n4);
+    return static_cast<int>(hipGetLastError());
+}
+
+int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
+    if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->K % TBK || a->N % 4) return static_cast<int>(hipErrorInvalidValue);
+    if (a->lda % 8 || a->ldw % 8 || a->lda < a->K || a->ldw < a->K || a->ldc < a->N || a->ldc % 4)
+        return static_cast<int>(hipErrorInvalidValue);
+    if (!aligned16(a->A) || !aligned16(a->W) || !aligned16(a->bias) || !aligned16(a->C))
+        return static_cast<int>(hipErrorInvalidValue);
+    if (a->epilogue == VITHIP_BF16_EPI_F32_RESIDUAL && (!a->residual || a->ldr < a->N || a->ldr % 4 || !aligned16(a->residual)))
+        return static_cast<int>(hipErrorInvalidValue);
+    Bf16Params p{};
+    p.A = a->A; p.W = a->W; p.bias = a->bias; p.R = a->residual; p.C = a->C;
+    p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.tiles_m = (p.M + TBM - 1) / TBM;
+    p.tiles_n = (p.N + TBN - 1) / TBN;
+    p.group_m = 8;
+    const dim3 grid(p.tiles_m * p.tiles_n), block(THREADS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (a->epilogue) {
+        case VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16>, grid, block, 0, s, p); break;
+        case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16_GELU>, grid, block, 0, s, p); break;
+        case VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_F32_RESIDUAL>, grid, block, 0, s, p); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // extern "C"
