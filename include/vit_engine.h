@@ -36,7 +36,10 @@ typedef struct {
     int max_batch;   /* images per forward chunk (workspace is sized for it); default 256 */
     int profile;     /* 1: bracket every stage with events and accumulate vit_stage_times */
     int lanes;       /* sub-batches of a chunk run concurrently on separate streams (1..4); default 1 */
+    int dtype;       /* VIT_DTYPE_F32 (default: the reference's arithmetic) or VIT_DTYPE_BF16 (bf16 MFMA GEMMs) */
 } vit_engine_options;
+
+enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };
 
 /* Per-stage device time of the profiled forwards (ms, summed) and launch counts. */
 enum {

@@ -118,6 +118,12 @@ typedef struct {
 } vithip_gemm_bf16_args;
 /* C = epilogue(A . W^T + bias) on v_mfma_f32_32x32x16_bf16, fp32 accumulate. */
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
+/* LayerNorm with fp32 statistics and a bf16 store; attention reading bf16 Q/K/V and writing bf16
+ * (K/V widened to fp32 in LDS, fp32 MFMA and softmax as vithip_attention_f32). */
+int vithip_layernorm_f32_bf16out(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *y, size_t ldy,
+                                 const float *gamma, const float *beta, int rows, int dim);
+int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
+                            int n_images, int tokens, int heads);
 /* dst[i] = bf16(src[i]), round to nearest even; count % 4 == 0. */
 int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short *dst, size_t count);
 

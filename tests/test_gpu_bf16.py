@@ -51,3 +51,58 @@ def test_gemm_bf16_bf16_out(oracle, epi):
     got = B.from_bf16_bits(B.gemm_bf16(Ab, Wb, b, epilogue=epi))
     err = np.abs(got - ref)
     assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), float(err.max())       # one bf16 rounding of the result
+
+
+def test_layernorm_bf16_out(oracle):
+    x = u(10, (197, 768), 3.0) + 0.5
+    g, b = synth.uniform(999, 11, 768, 0.5, 1.5), u(12, (768,), 0.5)
+    ref = oracle.layer_norm(x, g, b)
+    got = B.from_bf16_bits(B.layernorm_bf16out(x, g, b))
+    assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-5).all()          # one bf16 rounding
+
+
+@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (1, 50, 2), (1, 577, 2)])
+def test_attention_bf16_io(oracle, n, T, heads):
+    D = heads * 64
+    bits = B.to_bf16_bits(u(13, (n * T, 3 * D), 1.5))
+    qkv = B.from_bf16_bits(bits)                                               # the exact values the kernel sees
+    got = B.from_bf16_bits(B.attention_bf16io(bits, n, T, heads)).reshape(n, T, D)
+    for i in range(n):
+        blk = qkv[i * T:(i + 1) * T]
+        q, k, v = (np.ascontiguousarray(blk[:, j * D:(j + 1) * D]) for j in range(3))
+        ref = oracle.attention_core(q, k, v, heads)
+        assert (np.abs(got[i] - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-5).all()    # fp32 inside, one bf16 rounding out
+
+
+BF16_PROB_TOL = 2e-2   # bf16 activations carry 8 significant bits; the fp32 bar (1e-4) does not apply here
+
+
+@pytest.mark.parametrize("cfg,n", [(synth.VIT_TINY, 5), (synth.VIT_SMALL, 6)])
+def test_bf16_forward_small_models(oracle, cfg, n):
+    from conftest import oracle_config
+    W = synth.make_weights(cfg, 21)
+    eng = B.Engine(cfg, max_batch=4, dtype="bf16")
+    eng.load_weights(W)
+    imgs = synth.make_images(cfg, n, 100)
+    probs = eng.forward(imgs)
+    ref = oracle.forward(oracle_config(cfg), imgs, W)
+    assert float(np.abs(probs - ref).max()) <= BF16_PROB_TOL
+    assert (probs.argmax(1) == ref.argmax(1)).all()
+    eng.close()
+
+
+def test_bf16_forward_b16_vs_reference_golden():
+    """ViT-B/16 with bf16 MFMA GEMMs against the fp32 reference vectors: same top-1, probabilities within
+    BF16_PROB_TOL (measured 2.4e-3)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vit_b16_e2e.npz"))
+    cfg = synth.VIT_B16
+    eng = B.Engine(cfg, max_batch=8, dtype="bf16", lanes=2)
+    eng.load_weights(synth.make_weights(cfg, int(g["weight_seed"])))
+    imgs = synth.make_images(cfg, int(g["n_images"]), int(g["image_seed"]))
+    probs = eng.forward(imgs)
+    err = float(np.abs(probs - g["probs"]).max())
+    print("bf16 max |dprob| vs fp32 reference:", err)
+    assert err <= BF16_PROB_TOL
+    assert (probs.argmax(1) == g["probs"].argmax(1)).all()
+    eng.close()

@@ -46,7 +46,8 @@ class CImageData(C.Structure):  # Network.h:7-13
 
 
 class COptions(C.Structure):
-    _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int)]
+    _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
+                ("dtype", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -259,6 +260,31 @@ def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16) -> np
     return dC.numpy()
 
 
+def layernorm_bf16out(x, gamma, beta) -> np.ndarray:
+    """vithip_layernorm_f32_bf16out -> bf16 bits."""
+    x = _as_f32(x)
+    rows, dim = x.shape
+    L = lib()
+    L.vithip_layernorm_f32_bf16out.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    dx, dg, db = DeviceArray.from_numpy(x), DeviceArray.from_numpy(_as_f32(gamma)), DeviceArray.from_numpy(_as_f32(beta))
+    dy = DeviceArray((rows, dim), np.uint16)
+    hip_check(L.vithip_layernorm_f32_bf16out(None, dx.ptr, dim, dy.ptr, dim, dg.ptr, db.ptr, rows, dim),
+              "vithip_layernorm_f32_bf16out")
+    return dy.numpy()
+
+
+def attention_bf16io(qkv_bits, n_images: int, tokens: int, heads: int) -> np.ndarray:
+    """vithip_attention_bf16io on bf16 bit patterns -> bf16 bits."""
+    D = heads * 64
+    L = lib()
+    L.vithip_attention_bf16io.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    dq = DeviceArray.from_numpy(np.ascontiguousarray(qkv_bits, np.uint16))
+    do = DeviceArray((n_images * tokens, D), np.uint16)
+    hip_check(L.vithip_attention_bf16io(None, dq.ptr, do.ptr, n_images, tokens, heads), "vithip_attention_bf16io")
+    return do.numpy()
+
+
 def layernorm(x, gamma, beta) -> np.ndarray:
     x = _as_f32(x)
     rows, dim = x.shape
@@ -316,11 +342,11 @@ class Engine:
     """vit_engine (include/vit_engine.h): weights resident in HBM, batched forward."""
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
-                 lanes: int = 1):
+                 lanes: int = 1, dtype: str = "f32"):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
-        opt = COptions(device, max_batch, 1 if profile else 0, lanes)
+        opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype])
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

@@ -24,6 +24,30 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned short bf16_t;  // raw bf16 bits (bf16 variant of the forward: qkv and the output are bf16,
+                                // scores, softmax and accumulation stay fp32)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+template <typename IO> __device__ __forceinline__ f32x4 load4(const IO *p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t *p) {
+    const uint2 b = *reinterpret_cast<const uint2 *>(p);  // 4 bf16: value = bits << 16
+    f32x4 v;
+    v[0] = __uint_as_float(b.x << 16);
+    v[1] = __uint_as_float(b.x & 0xffff0000u);
+    v[2] = __uint_as_float(b.y << 16);
+    v[3] = __uint_as_float(b.y & 0xffff0000u);
+    return v;
+}
+template <typename IO> __device__ __forceinline__ void store4(IO *p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (__bf16)v[q];
+    *reinterpret_cast<bf16x4 *>(p) = o;
+}
+
 constexpr int HD = 64;          // head_dim (ViT-B/16 and ViT-L/16)
 constexpr int K_LD = HD + 4;    // padded K row (floats): conflict-free ds_read_b128 over 32 rows
 constexpr int ATT_THREADS = 512;
@@ -31,9 +55,9 @@ constexpr int ATT_WAVES = ATT_THREADS / 64;
 
 unsigned long long *g_attn_dbg = nullptr;  // see vithip_attention_set_debug_buffer()
 
-template <int NKT>  // number of 32-key tiles: tokens <= 32*NKT
-__global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float *__restrict__ qkv,
-                                                                    float *__restrict__ out,
+template <int NKT, typename IO>  // NKT = number of 32-key tiles: tokens <= 32*NKT; IO = float or bf16 bits
+__global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const IO *__restrict__ qkv,
+                                                                    IO *__restrict__ out,
                                                                     int tokens, int heads,
                                                                     unsigned long long *__restrict__ dbg) {
     // dbg != nullptr (tools/attn_probe.py --stamps): cycle stamps of wave 0 at the phase boundaries
@@ -48,7 +72,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
     const int head = blockIdx.x, img = blockIdx.y;
     const int D = heads * HD, ld = 3 * D;
     const int tid = threadIdx.x;
-    const float *base = qkv + (size_t)img * tokens * ld + head * HD;
+    const IO *base = qkv + (size_t)img * tokens * ld + head * HD;
 
     // ---- stage K and V of this head: 16 float4 per row, rows >= tokens are zero ----------
     // All loads of a thread are issued before the first LDS store, so the ~100 KB of a head arrive
@@ -61,9 +85,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
         for (int it = 0; it < NKT; ++it) {
             const int row = (tid >> 4) + it * ROWS_PER_PASS;
             const int srow = row < tokens ? row : tokens - 1;  // clamped address, value discarded below
-            const float *src = base + (size_t)srow * ld + c4;
-            kreg[it] = *reinterpret_cast<const f32x4 *>(src + D);
-            vreg[it] = *reinterpret_cast<const f32x4 *>(src + 2 * D);
+            const IO *src = base + (size_t)srow * ld + c4;
+            kreg[it] = load4<IO>(src + D);
+            vreg[it] = load4<IO>(src + 2 * D);
         }
 #pragma unroll
         for (int it = 0; it < NKT; ++it) {
@@ -89,9 +113,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
         {
             int qrow = q0 + r;
             qrow = qrow < tokens ? qrow : tokens - 1;
-            const float *qsrc = base + (size_t)qrow * ld + h * 4;
+            const IO *qsrc = base + (size_t)qrow * ld + h * 4;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4 *>(qsrc + c * 8);
+            for (int c = 0; c < 8; ++c) qf[c] = load4<IO>(qsrc + c * 8);
         }
 
         // ---- S^T = K . Q^T -----------------------------------------------------------
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
         if (dbg) t4 = __builtin_amdgcn_s_memtime();
         // ---- store: lane owns query q0+r; registers 4g..4g+3 are 4 consecutive d ---------
         if (q0 + r < tokens) {
-            float *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+            IO *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
                     w[1] = o[dt][4 * g + 1] * inv;
                     w[2] = o[dt][4 * g + 2] * inv;
                     w[3] = o[dt][4 * g + 3] * inv;
-                    *reinterpret_cast<f32x4 *>(dst + dt * 32 + 8 * g) = w;
+                    store4<IO>(dst + dt * 32 + 8 * g, w);
                 }
         }
     }
@@ -224,8 +248,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const float 
 constexpr int CKT = 7;           // key tiles per chunk
 constexpr int CKEYS = CKT * 32;  // 224 keys per chunk
 
-__global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(const float *__restrict__ qkv,
-                                                                            float *__restrict__ out, int tokens,
+template <typename IO>
+__global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(const IO *__restrict__ qkv,
+                                                                            IO *__restrict__ out, int tokens,
                                                                             int heads) {
     __shared__ __attribute__((aligned(16))) float lds[CKEYS * K_LD + CKEYS * HD];
     float *const Vs = lds;
@@ -236,7 +261,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const float *base = qkv + (size_t)img * tokens * ld + head * HD;
+    const IO *base = qkv + (size_t)img * tokens * ld + head * HD;
 
     const int q0 = (blockIdx.z * ATT_WAVES + wave) * 32;
     const bool active = q0 < tokens;  // wave-uniform
@@ -245,9 +270,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
     {
         int qrow = q0 + r;
         qrow = qrow < tokens ? qrow : tokens - 1;
-        const float *qsrc = base + (size_t)qrow * ld + h * 4;
+        const IO *qsrc = base + (size_t)qrow * ld + h * 4;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4 *>(qsrc + c * 8);
+        for (int c = 0; c < 8; ++c) qf[c] = load4<IO>(qsrc + c * 8);
     }
     f32x16 o[2];
 #pragma unroll
@@ -271,9 +296,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
             for (int it = 0; it < CKT; ++it) {
                 const int row = (tid >> 4) + it * ROWS_PER_PASS;
                 const int srow = key_base + (row < ckeys ? row : ckeys - 1);
-                const float *src = base + (size_t)srow * ld + c4;
-                kreg[it] = *reinterpret_cast<const f32x4 *>(src + D);
-                vreg[it] = *reinterpret_cast<const f32x4 *>(src + 2 * D);
+                const IO *src = base + (size_t)srow * ld + c4;
+                kreg[it] = load4<IO>(src + D);
+                vreg[it] = load4<IO>(src + 2 * D);
             }
 #pragma unroll
             for (int it = 0; it < CKT; ++it) {
@@ -361,7 +386,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
     if (active && q0 + r < tokens) {
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
-        float *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+        IO *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -371,16 +396,39 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
                 w[1] = o[dt][4 * g + 1] * inv;
                 w[2] = o[dt][4 * g + 2] * inv;
                 w[3] = o[dt][4 * g + 3] * inv;
-                *reinterpret_cast<f32x4 *>(dst + dt * 32 + 8 * g) = w;
+                store4<IO>(dst + dt * 32 + 8 * g, w);
             }
     }
 }
 
-template <int NKT>
-int launch(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads) {
-    hipLaunchKernelGGL(attention_f32_kernel<NKT>, dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out,
+template <int NKT, typename IO>
+int launch(hipStream_t s, const IO *qkv, IO *out, int n_images, int tokens, int heads) {
+    hipLaunchKernelGGL((attention_f32_kernel<NKT, IO>), dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out,
                        tokens, heads, g_attn_dbg);
     return static_cast<int>(hipGetLastError());
+}
+
+template <typename IO>
+int attention_dispatch(hipStream_t s, const IO *qkv, IO *out, int n_images, int tokens, int heads) {
+    if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0) return static_cast<int>(hipErrorInvalidValue);
+    if ((reinterpret_cast<size_t>(qkv) & 15) || (reinterpret_cast<size_t>(out) & 15))
+        return static_cast<int>(hipErrorInvalidValue);
+    const int nkt = (tokens + 31) / 32;
+    switch (nkt) {
+        case 1: return launch<1, IO>(s, qkv, out, n_images, tokens, heads);
+        case 2: return launch<2, IO>(s, qkv, out, n_images, tokens, heads);
+        case 3: return launch<3, IO>(s, qkv, out, n_images, tokens, heads);
+        case 4: return launch<4, IO>(s, qkv, out, n_images, tokens, heads);
+        case 5: return launch<5, IO>(s, qkv, out, n_images, tokens, heads);
+        case 6: return launch<6, IO>(s, qkv, out, n_images, tokens, heads);
+        case 7: return launch<7, IO>(s, qkv, out, n_images, tokens, heads);
+        default: {  // > 224 tokens: K/V stream through LDS in chunks, online softmax
+            const int qblocks = (nkt + ATT_WAVES - 1) / ATT_WAVES;
+            hipLaunchKernelGGL(attention_f32_chunked_kernel<IO>, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s,
+                               qkv, out, tokens, heads);
+            return static_cast<int>(hipGetLastError());
+        }
+    }
 }
 
 }  // namespace
@@ -393,24 +441,12 @@ extern "C" int vithip_attention_set_debug_buffer(void *buf) {
 
 extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
                                     int n_images, int tokens, int heads) {
-    if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0) return static_cast<int>(hipErrorInvalidValue);
-    if ((reinterpret_cast<size_t>(qkv) & 15) || (reinterpret_cast<size_t>(out) & 15))
-        return static_cast<int>(hipErrorInvalidValue);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nkt = (tokens + 31) / 32;
-    switch (nkt) {
-        case 1: return launch<1>(s, qkv, out, n_images, tokens, heads);
-        case 2: return launch<2>(s, qkv, out, n_images, tokens, heads);
-        case 3: return launch<3>(s, qkv, out, n_images, tokens, heads);
-        case 4: return launch<4>(s, qkv, out, n_images, tokens, heads);
-        case 5: return launch<5>(s, qkv, out, n_images, tokens, heads);
-        case 6: return launch<6>(s, qkv, out, n_images, tokens, heads);
-        case 7: return launch<7>(s, qkv, out, n_images, tokens, heads);
-        default: {  // > 224 tokens: K/V stream through LDS in chunks, online softmax
-            const int qblocks = (nkt + ATT_WAVES - 1) / ATT_WAVES;
-            hipLaunchKernelGGL(attention_f32_chunked_kernel, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s,
-                               qkv, out, tokens, heads);
-            return static_cast<int>(hipGetLastError());
-        }
-    }
+    return attention_dispatch<float>(static_cast<hipStream_t>(stream), qkv, out, n_images, tokens, heads);
+}
+
+// bf16 variant: qkv and out hold bf16 bits; K/V are widened to fp32 while staged into LDS and all
+// arithmetic (fp32 MFMA, softmax) is the same as above; the output is rounded to bf16 once.
+extern "C" int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
+                                       int n_images, int tokens, int heads) {
+    return attention_dispatch<bf16_t>(static_cast<hipStream_t>(stream), qkv, out, n_images, tokens, heads);
 }

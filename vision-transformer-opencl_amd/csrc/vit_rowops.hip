@@ -29,9 +29,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-template <int NVEC>
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+// OUT = float, or unsigned short (bf16 bits) for the bf16 variant of the forward: statistics and the
+// affine map are fp32 either way, only the store rounds.
+template <int NVEC, typename OUT>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_f32_kernel(const float *__restrict__ x, size_t ldx,
-                                                                   float *__restrict__ y, size_t ldy,
+                                                                   OUT *__restrict__ y, size_t ldy,
                                                                    const float *__restrict__ gamma,
                                                                    const float *__restrict__ beta,
                                                                    int rows, int dim) {
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_f32_kernel(const float *
         const float mean = s / (float)dim;
         const float var = ss / (float)dim - mean * mean;
         const float inv_std = 1.0f / sqrtf((float)((double)var + 1e-6));
-        float *dst = y + (size_t)row * ldy;
+        OUT *dst = y + (size_t)row * ldy;
 #pragma unroll
         for (int i = 0; i < NVEC; ++i) {
             const int c = (i * 64 + lane) * 4;
@@ -66,7 +70,14 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_f32_kernel(const float *
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * inv_std * g[j] + b[j];
-                *reinterpret_cast<f32x4 *>(dst + c) = o;
+                if constexpr (sizeof(OUT) == 4) {
+                    *reinterpret_cast<f32x4 *>(dst + c) = o;
+                } else {
+                    bf16x4 ob;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
+                    *reinterpret_cast<bf16x4 *>(dst + c) = ob;
+                }
             }
         }
     }
@@ -134,23 +145,20 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_top1_f32_kernel(const floa
     }
 }
 
-template <int NVEC>
-int launch_ln(hipStream_t s, const float *x, size_t ldx, float *y, size_t ldy, const float *gamma,
+template <int NVEC, typename OUT>
+int launch_ln(hipStream_t s, const float *x, size_t ldx, OUT *y, size_t ldy, const float *gamma,
               const float *beta, int rows, int dim) {
     const int rows_per_block = LN_THREADS / 64;
     int blocks = (rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
-    hipLaunchKernelGGL(layernorm_f32_kernel<NVEC>, dim3(blocks), dim3(LN_THREADS), 0, s, x, ldx, y, ldy, gamma,
+    hipLaunchKernelGGL((layernorm_f32_kernel<NVEC, OUT>), dim3(blocks), dim3(LN_THREADS), 0, s, x, ldx, y, ldy, gamma,
                        beta, rows, dim);
     return static_cast<int>(hipGetLastError());
 }
 
-}  // namespace
-
-extern "C" {
-
-int vithip_layernorm_f32(vithip_stream_t stream, const float *x, size_t ldx, float *y, size_t ldy,
-                         const float *gamma, const float *beta, int rows, int dim) {
+template <typename OUT>
+int layernorm_dispatch(vithip_stream_t stream, const float *x, size_t ldx, OUT *y, size_t ldy, const float *gamma,
+                       const float *beta, int rows, int dim) {
     if (!x || !y || !gamma || !beta || rows <= 0 || dim <= 0) return static_cast<int>(hipErrorInvalidValue);
     if (dim % 4 || dim > 64 * 4 * LN_MAX_VEC || ldx % 4 || ldy % 4) return static_cast<int>(hipErrorInvalidValue);
     if ((reinterpret_cast<size_t>(x) & 15) || (reinterpret_cast<size_t>(y) & 15) ||
@@ -159,12 +167,26 @@ int vithip_layernorm_f32(vithip_stream_t stream, const float *x, size_t ldx, flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nvec = (dim + 255) / 256;
     switch (nvec) {
-        case 1: return launch_ln<1>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
-        case 2: return launch_ln<2>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
-        case 3: return launch_ln<3>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
-        case 4: return launch_ln<4>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
-        default: return launch_ln<LN_MAX_VEC>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
+        case 1: return launch_ln<1, OUT>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
+        case 2: return launch_ln<2, OUT>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
+        case 3: return launch_ln<3, OUT>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
+        case 4: return launch_ln<4, OUT>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
+        default: return launch_ln<LN_MAX_VEC, OUT>(s, x, ldx, y, ldy, gamma, beta, rows, dim);
     }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vithip_layernorm_f32(vithip_stream_t stream, const float *x, size_t ldx, float *y, size_t ldy,
+                         const float *gamma, const float *beta, int rows, int dim) {
+    return layernorm_dispatch<float>(stream, x, ldx, y, ldy, gamma, beta, rows, dim);
+}
+
+int vithip_layernorm_f32_bf16out(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *y, size_t ldy,
+                                 const float *gamma, const float *beta, int rows, int dim) {
+    return layernorm_dispatch<unsigned short>(stream, x, ldx, y, ldy, gamma, beta, rows, dim);
 }
 
 int vithip_softmax_top1_f32(vithip_stream_t stream, const float *logits, int ld_logits, float *probs,

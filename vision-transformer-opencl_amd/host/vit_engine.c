@@ -37,6 +37,8 @@ struct vit_engine {
     vithip_event_t ev_fork, ev_join[VIT_MAX_LANES - 1];
     float *wblob;                /* all weights, one allocation */
     float **w;                   /* device pointer per weight index */
+    unsigned short *wblob16;     /* bf16 copies of the GEMM weights (dtype bf16 only) */
+    unsigned short **w16;        /* per weight index; NULL for tensors that stay fp32 */
     int weights_loaded;
 
     /* workspace for max_batch images */
@@ -103,6 +105,7 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->max_batch = 256;
     opt->profile = 0;
     opt->lanes = 1;
+    opt->dtype = VIT_DTYPE_F32;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -188,7 +191,12 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
     }
 
     e->w = (float **)calloc((size_t)e->n_weights, sizeof(float *));
-    if (!e->w) return fail(e, VIT_ERR_NOMEM, "out of host memory");
+    e->w16 = (unsigned short **)calloc((size_t)e->n_weights, sizeof(unsigned short *));
+    if (!e->w || !e->w16) return fail(e, VIT_ERR_NOMEM, "out of host memory");
+    if (e->opt.dtype != VIT_DTYPE_F32 && e->opt.dtype != VIT_DTYPE_BF16)
+        return fail(e, VIT_ERR_ARG, "dtype must be VIT_DTYPE_F32 or VIT_DTYPE_BF16");
+    if (e->opt.dtype == VIT_DTYPE_BF16 && (e->cfg.embed_dim % 64 || e->cfg.hidden_dim % 64))
+        return fail(e, VIT_ERR_ARG, "bf16 path needs embed_dim and hidden_dim to be multiples of 64");
     if (e->opt.profile) return vit_engine_set_profile(e, 1);
     return VIT_OK;
 }
@@ -209,6 +217,8 @@ void vit_engine_destroy(vit_engine *e) {
         if (e->ev_done[b]) vithip_event_destroy(e->ev_done[b]);
     }
     vithip_free(e->wblob);
+    vithip_free(e->wblob16);
+    free(e->w16);
     for (int j = 0; j < VIT_MAX_LANES - 1; ++j) {
         if (e->aux_stream[j]) { vithip_stream_sync(e->aux_stream[j]); vithip_stream_destroy(e->aux_stream[j]); }
         if (e->ev_join[j]) vithip_event_destroy(e->ev_join[j]);
@@ -259,6 +269,24 @@ int vit_engine_load_weights(vit_engine *e, const Network *weights, int count) {
         HIP_TRY(e, vithip_memcpy_h2d(e->w[i], weights[i].data, weights[i].size * sizeof(float), e->stream));
         off += (weights[i].size + 63) & ~(size_t)63;
     }
+    if (e->opt.dtype == VIT_DTYPE_BF16) {
+        /* bf16 copies of the four GEMM weights of every layer (in_proj, out_proj, fc1, fc2), converted on
+         * the device from the rounded fp32 upload (round to nearest even); everything else stays fp32 */
+        static const int gemm_slots[4] = {2, 4, 8, 10};
+        size_t total16 = 0;
+        for (int l = 0; l < e->cfg.depth; ++l)
+            for (int k = 0; k < 4; ++k) total16 += (weights[4 + VIT_WEIGHTS_PER_LAYER * l + gemm_slots[k]].size + 63) & ~(size_t)63;
+        if (e->wblob16) { vithip_free(e->wblob16); e->wblob16 = NULL; }
+        HIP_TRY(e, vithip_malloc((void **)&e->wblob16, total16 * sizeof(unsigned short)));
+        size_t off16 = 0;
+        for (int l = 0; l < e->cfg.depth; ++l)
+            for (int k = 0; k < 4; ++k) {
+                const int idx = 4 + VIT_WEIGHTS_PER_LAYER * l + gemm_slots[k];
+                e->w16[idx] = e->wblob16 + off16;
+                HIP_TRY(e, vithip_f32_to_bf16(e->stream, e->w[idx], e->w16[idx], weights[idx].size));
+                off16 += (weights[idx].size + 63) & ~(size_t)63;
+            }
+    }
     HIP_TRY(e, vithip_stream_sync(e->stream));
     e->weights_loaded = 1;
     return VIT_OK;
@@ -285,6 +313,17 @@ static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_f32(s, &a));
+    HIP_TRY(e, stage_end(e, s));
+    return VIT_OK;
+}
+
+static int gemm16(vit_engine *e, vithip_stream_t s, int stage, const unsigned short *A, int lda, const unsigned short *W,
+                  const float *bias, const float *res, void *C, int ldc, int M, int N, int K, int epi) {
+    vithip_gemm_bf16_args a;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
+    a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
+    HIP_TRY(e, stage_begin(e, s, stage));
+    HIP_TRY(e, vithip_gemm_bf16(s, &a));
     HIP_TRY(e, stage_end(e, s));
     return VIT_OK;
 }
@@ -350,7 +389,45 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
                                           e->x + ROWS(j) * D, lane[j].n, c->img_size, c->patch_size, c->in_chans, D));
         HIP_TRY(e, stage_end(e, lane[j].s));
     }
-    for (int l = 0; l < c->depth; ++l) {
+    const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
+    /* bf16 variant: LN output, qkv, attention output and the MLP hidden layer are bf16 (they live in the same
+     * allocations, half used); the residual stream x, LayerNorm statistics, softmax and every accumulation
+     * stay fp32; patch embedding and the classifier head run the fp32 kernels. */
+    unsigned short *y16 = (unsigned short *)e->y, *qkv16 = (unsigned short *)e->qkv, *h16 = (unsigned short *)e->hbuf;
+    for (int l = 0; l < c->depth && bf16; ++l) {
+        float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
+        unsigned short **lw16 = e->w16 + 4 + VIT_WEIGHTS_PER_LAYER * l;
+        LANES {
+            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+            HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)D, y16 + ROWS(j) * D, (size_t)D,
+                                                    lw[0], lw[1], lane[j].n * T, D));
+            HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        LANES
+            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_QKV, y16 + ROWS(j) * D, D, lw16[2], lw[3], NULL,
+                             qkv16 + ROWS(j) * 3 * D, 3 * D, lane[j].n * T, 3 * D, D, VITHIP_BF16_EPI_BF16))) return rc;
+        LANES {
+            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
+            HIP_TRY(e, vithip_attention_bf16io(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T, c->num_heads));
+            HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        LANES
+            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, D, lw16[4], lw[5], e->x + ROWS(j) * D,
+                             e->x + ROWS(j) * D, D, lane[j].n * T, D, D, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
+        LANES {
+            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+            HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)D, y16 + ROWS(j) * D, (size_t)D,
+                                                    lw[6], lw[7], lane[j].n * T, D));
+            HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        LANES
+            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC1, y16 + ROWS(j) * D, D, lw16[8], lw[9], NULL,
+                             h16 + ROWS(j) * H, H, lane[j].n * T, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
+        LANES
+            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
+                             e->x + ROWS(j) * D, D, lane[j].n * T, D, H, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
+    }
+    for (int l = 0; l < c->depth && !bf16; ++l) {
         float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
         LANES { /* LN1 (ViT_seq.c:281) */
             HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
