@@ -124,6 +124,8 @@ int vithip_layernorm_f32_bf16out(vithip_stream_t stream, const float *x, size_t 
                                  const float *gamma, const float *beta, int rows, int dim);
 int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
                             int n_images, int tokens, int heads);
+/* 1 (default): tokens <= 224 run both attention products on bf16 MFMA (P rounded to bf16); 0: fp32 MFMA. */
+int vithip_attention_bf16_set_mfma(int on);
 /* dst[i] = bf16(src[i]), round to nearest even; count % 4 == 0. */
 int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short *dst, size_t count);
 

@@ -61,17 +61,26 @@ def test_layernorm_bf16_out(oracle):
     assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-5).all()          # one bf16 rounding
 
 
-@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (1, 50, 2), (1, 577, 2)])
-def test_attention_bf16_io(oracle, n, T, heads):
+@pytest.mark.parametrize("mfma", [1, 0], ids=["bf16-mfma", "fp32-mfma"])
+@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (1, 50, 2), (1, 224, 1), (1, 33, 1), (1, 577, 2)])
+def test_attention_bf16_io(oracle, n, T, heads, mfma):
+    """bf16 Q/K/V in, bf16 out.  mfma=1: both products on bf16 MFMA, P rounded to bf16 (tokens <= 224);
+    mfma=0: fp32 MFMA on the widened values (also what sequences > 224 tokens use)."""
     D = heads * 64
     bits = B.to_bf16_bits(u(13, (n * T, 3 * D), 1.5))
     qkv = B.from_bf16_bits(bits)                                               # the exact values the kernel sees
-    got = B.from_bf16_bits(B.attention_bf16io(bits, n, T, heads)).reshape(n, T, D)
+    B.lib().vithip_attention_bf16_set_mfma(mfma)
+    try:
+        got = B.from_bf16_bits(B.attention_bf16io(bits, n, T, heads)).reshape(n, T, D)
+    finally:
+        B.lib().vithip_attention_bf16_set_mfma(1)
+    # fp32 inside + one bf16 rounding of the output; with bf16 P add sum_j |dp_j v_j| <~ 2^-9 |v| sqrt(sum p^2)
+    slack = 1e-3 if (mfma and T <= 224) else 2e-5
     for i in range(n):
         blk = qkv[i * T:(i + 1) * T]
         q, k, v = (np.ascontiguousarray(blk[:, j * D:(j + 1) * D]) for j in range(3))
         ref = oracle.attention_core(q, k, v, heads)
-        assert (np.abs(got[i] - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-5).all()    # fp32 inside, one bf16 rounding out
+        assert (np.abs(got[i] - ref) <= 2.0 ** -8 * np.abs(ref) + slack).all(), float(np.abs(got[i] - ref).max())
 
 
 BF16_PROB_TOL = 2e-2   # bf16 activations carry 8 significant bits; the fp32 bar (1e-4) does not apply here

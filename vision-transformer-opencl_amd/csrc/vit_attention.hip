@@ -54,6 +54,7 @@ constexpr int ATT_THREADS = 512;
 constexpr int ATT_WAVES = ATT_THREADS / 64;
 
 unsigned long long *g_attn_dbg = nullptr;  // see vithip_attention_set_debug_buffer()
+int g_attn_bf16_mfma = 1;                  // see vithip_attention_bf16_set_mfma()
 
 template <int NKT, typename IO>  // NKT = number of 32-key tiles: tokens <= 32*NKT; IO = float or bf16 bits
 __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const IO *__restrict__ qkv,
@@ -401,6 +402,176 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16 MFMA attention for the bf16 variant (tokens <= 224).  Same structure as attention_f32_kernel,
+// but both products run on v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate), which turns the kernel
+// from matrix-bound into HBM-bound (2.5 GB of qkv/out per layer at batch 2048):
+//   * K of the head sits in LDS as bf16 rows of 128 B with the GEMM's XOR swizzle (conflict-free
+//     ds_read_b128 of the A fragments);
+//   * V sits TRANSPOSED (Vt[d][key], 456-B rows: conflict-free ds_read_b64), because the P.V product
+//     needs, per lane, 8 keys of one d as its A fragment;
+//   * P goes from the S^T accumulator to the B operand of P.V in registers: registers 8s..8s+7 of a
+//     32x32 accumulator, packed to bf16, are exactly the k-step-s fragment whose element j of lane half h
+//     is key 16s + 8(j>>2) + 4h + (j&3) -- the V^T fragment is gathered in that same order.
+// Softmax, max and sums are fp32; P is rounded to bf16 once (the documented cost of the bf16 variant).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int VT_LD = 228;  // Vt row length in bf16 (224 keys + 4): 456 B = 114 dwords, 114 % 64 = 50 -> conflict-free b64
+
+template <int NKT>
+__global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_t *__restrict__ qkv,
+                                                                     bf16_t *__restrict__ out, int tokens, int heads) {
+    constexpr int KEYS = NKT * 32;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[KEYS * HD + HD * VT_LD];
+    bf16_t *const Ks = lds;                 // [KEYS][64], chunk-swizzled
+    bf16_t *const Vt = lds + KEYS * HD;     // [64][VT_LD]
+
+    const int head = blockIdx.x, img = blockIdx.y;
+    const int D = heads * HD, ld = 3 * D;
+    const int tid = threadIdx.x;
+    const bf16_t *base = qkv + (size_t)img * tokens * ld + head * HD;
+
+    // ---- stage K (swizzled rows) and V (transposed); everything past `tokens` is zero -------------
+    {
+        const int c8 = tid & 7;                  // 16-B chunk (8 bf16) of a 128-B row
+        constexpr int ROWS_PER_PASS = ATT_THREADS / 8;  // 64
+        constexpr int PASSES = (KEYS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+        uint4 kreg[PASSES], vreg[PASSES];
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int row = (tid >> 3) + it * ROWS_PER_PASS;
+            const int srow = row < tokens ? row : tokens - 1;
+            const bf16_t *src = base + (size_t)srow * ld + c8 * 8;
+            kreg[it] = *reinterpret_cast<const uint4 *>(src + D);
+            vreg[it] = *reinterpret_cast<const uint4 *>(src + 2 * D);
+        }
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int row = (tid >> 3) + it * ROWS_PER_PASS;
+            if (row < KEYS) {
+                const bool ok = row < tokens;
+                const uint4 zero = {0u, 0u, 0u, 0u};
+                const uint4 kv = ok ? kreg[it] : zero, vv = ok ? vreg[it] : zero;
+                *reinterpret_cast<uint4 *>(Ks + row * HD + ((c8 ^ ((row >> 1) & 7)) * 8)) = kv;
+                const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    Vt[(c8 * 8 + 2 * q) * VT_LD + row] = (bf16_t)(w[q] & 0xffffu);
+                    Vt[(c8 * 8 + 2 * q + 1) * VT_LD + row] = (bf16_t)(w[q] >> 16);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nqt = (tokens + 31) >> 5;
+    if (wave < nqt) {
+        const int q0 = wave * 32;
+        bf16x8 qf[4];
+        {
+            int qrow = q0 + r;
+            qrow = qrow < tokens ? qrow : tokens - 1;
+            const bf16_t *qsrc = base + (size_t)qrow * ld + h * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qsrc + ks * 16);
+        }
+
+        // ---- S^T = K . Q^T ------------------------------------------------------------------------
+        f32x16 st[NKT];
+        const int sw = (r >> 1) & 7;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) st[kt][v] = 0.0f;
+            const bf16_t *krow = Ks + (kt * 32 + r) * HD;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + h) ^ sw) & 7) * 8);
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kt], 0, 0, 0);
+            }
+        }
+
+        // ---- row softmax (fp32) ---------------------------------------------------------------------
+        float mx = -INFINITY;
+        const int rem = tokens - (NKT - 1) * 32;
+        const int h4 = 4 * h;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                if (kt == NKT - 1) {
+                    const int kloc = (v & 3) + 8 * (v >> 2);
+                    st[kt][v] = h4 < rem - kloc ? st[kt][v] : -INFINITY;
+                }
+                mx = fmaxf(mx, st[kt][v]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        constexpr float kScale = 0.125f * 1.4426950408889634f;
+        const float mxs = -mx * kScale;
+        float sum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
+                st[kt][v] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T = V^T . P^T --------------------------------------------------------------------------
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[dt][v] = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (kt < NKT - 1 || kt * 32 + 16 * s2 < tokens) {  // wave-uniform: skip 16-key blocks past the end
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][8 * s2 + j];
+                    const int key0 = kt * 32 + 16 * s2 + 4 * h;  // keys key0..+3 and key0+8..+11
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const bf16_t *vrow = Vt + (dt * 32 + r) * VT_LD + key0;
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
+                        const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 8);
+                        const uint4 packed = {lo.x, lo.y, hi.x, hi.y};
+                        const bf16x8 vf = __builtin_bit_cast(bf16x8, packed);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        if (q0 + r < tokens) {
+            bf16_t *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w;
+                    w[0] = o[dt][4 * g + 0] * inv;
+                    w[1] = o[dt][4 * g + 1] * inv;
+                    w[2] = o[dt][4 * g + 2] * inv;
+                    w[3] = o[dt][4 * g + 3] * inv;
+                    store4<bf16_t>(dst + dt * 32 + 8 * g, w);
+                }
+        }
+    }
+}
+
+template <int NKT>
+int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads) {
+    hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <int NKT, typename IO>
 int launch(hipStream_t s, const IO *qkv, IO *out, int n_images, int tokens, int heads) {
     hipLaunchKernelGGL((attention_f32_kernel<NKT, IO>), dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out,
@@ -448,5 +619,27 @@ extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, fl
 // arithmetic (fp32 MFMA, softmax) is the same as above; the output is rounded to bf16 once.
 extern "C" int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
                                        int n_images, int tokens, int heads) {
-    return attention_dispatch<bf16_t>(static_cast<hipStream_t>(stream), qkv, out, n_images, tokens, heads);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0 || (reinterpret_cast<size_t>(qkv) & 15) ||
+        (reinterpret_cast<size_t>(out) & 15))
+        return static_cast<int>(hipErrorInvalidValue);
+    if (g_attn_bf16_mfma) {  // bf16 matrix path while K/V of a head fit LDS; longer sequences use the chunked kernel
+        switch ((tokens + 31) / 32) {
+            case 1: return launch_bf16<1>(s, qkv, out, n_images, tokens, heads);
+            case 2: return launch_bf16<2>(s, qkv, out, n_images, tokens, heads);
+            case 3: return launch_bf16<3>(s, qkv, out, n_images, tokens, heads);
+            case 4: return launch_bf16<4>(s, qkv, out, n_images, tokens, heads);
+            case 5: return launch_bf16<5>(s, qkv, out, n_images, tokens, heads);
+            case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads);
+            case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads);
+            default: break;
+        }
+    }
+    return attention_dispatch<bf16_t>(s, qkv, out, n_images, tokens, heads);
+}
+
+// Tuning/test hook: 0 = keep the fp32-MFMA kernel for bf16 I/O, 1 (default) = bf16 MFMA attention.
+extern "C" int vithip_attention_bf16_set_mfma(int on) {
+    g_attn_bf16_mfma = on ? 1 : 0;
+    return 0;
 }
