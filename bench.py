@@ -62,6 +62,8 @@ def main() -> None:
                     help="concurrent sub-batches per step (engine option; 1 = every kernel alone on the GPU)")
     ap.add_argument("--kernel-steps", type=int, default=3,
                     help="extra steps with lanes=1 and per-launch event brackets for the roofline object (when lanes > 1)")
+    ap.add_argument("--model", choices=("b16", "l16_384"), default="b16",
+                    help="b16 = ViT-B/16 224 (the metric); l16_384 = ViT-L/16 384 (BASELINE.json configs[4], use --dtype bf16 --batch 1024)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the metric configuration (BASELINE.json configs[1]); bf16 = configs[2] (use --batch 2048)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
@@ -74,7 +76,7 @@ def main() -> None:
     pkg = importlib.import_module("vision-transformer-opencl_amd")
     binding = importlib.import_module("vision-transformer-opencl_amd.binding")
     synth = pkg.synth
-    cfg = pkg.VIT_B16
+    cfg = pkg.VIT_B16 if args.model == "b16" else pkg.VIT_L16_384
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -222,8 +224,9 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": (f"ViT-B/16 224x224 {'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} forward, batch {B} per GPU, "
-                                    "synthetic weights and images (BASELINE.json configs[%d])" % (1 if args.dtype == "f32" else 2)),
+            "config": {"workload": (f"{'ViT-B/16 224x224' if args.model == 'b16' else 'ViT-L/16 384x384'} "
+                                    f"{'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} forward, batch {B} per GPU, synthetic weights and images "
+                                    "(BASELINE.json configs[%d])" % (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2))),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                        "gflop_per_image": round(gflop_img, 4), "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},

@@ -62,10 +62,10 @@ def test_layernorm_bf16_out(oracle):
 
 
 @pytest.mark.parametrize("mfma", [1, 0], ids=["bf16-mfma", "fp32-mfma"])
-@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (1, 50, 2), (1, 224, 1), (1, 33, 1), (1, 577, 2)])
+@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (1, 50, 2), (1, 224, 1), (1, 33, 1), (1, 577, 2), (2, 300, 1), (1, 225, 1)])
 def test_attention_bf16_io(oracle, n, T, heads, mfma):
-    """bf16 Q/K/V in, bf16 out.  mfma=1: both products on bf16 MFMA, P rounded to bf16 (tokens <= 224);
-    mfma=0: fp32 MFMA on the widened values (also what sequences > 224 tokens use)."""
+    """bf16 Q/K/V in, bf16 out.  mfma=1: both products on bf16 MFMA, P rounded to bf16 (resident kernel up to
+    224 tokens, chunked online-softmax kernel beyond); mfma=0: fp32 MFMA on the widened values."""
     D = heads * 64
     bits = B.to_bf16_bits(u(13, (n * T, 3 * D), 1.5))
     qkv = B.from_bf16_bits(bits)                                               # the exact values the kernel sees
@@ -75,7 +75,7 @@ def test_attention_bf16_io(oracle, n, T, heads, mfma):
     finally:
         B.lib().vithip_attention_bf16_set_mfma(1)
     # fp32 inside + one bf16 rounding of the output; with bf16 P add sum_j |dp_j v_j| <~ 2^-9 |v| sqrt(sum p^2)
-    slack = 1e-3 if (mfma and T <= 224) else 2e-5
+    slack = 1e-3 if mfma else 2e-5
     for i in range(n):
         blk = qkv[i * T:(i + 1) * T]
         q, k, v = (np.ascontiguousarray(blk[:, j * D:(j + 1) * D]) for j in range(3))
@@ -114,4 +114,20 @@ def test_bf16_forward_b16_vs_reference_golden():
     print("bf16 max |dprob| vs fp32 reference:", err)
     assert err <= BF16_PROB_TOL
     assert (probs.argmax(1) == g["probs"].argmax(1)).all()
+    eng.close()
+
+
+def test_bf16_forward_vit_l_geometry(oracle):
+    """ViT-L/16-384 width and sequence length (D=1024, 16 heads, H=4096, 577 tokens), 2 layers, bf16 GEMMs
+    (K = 1024 / 4096) + the chunked attention with bf16 I/O, against the fp32 oracle."""
+    from conftest import oracle_config
+    cfg = synth.ModelConfig(img_size=384, embed_dim=1024, depth=2, num_heads=16, hidden_dim=4096)
+    W = synth.make_weights(cfg, 31)
+    eng = B.Engine(cfg, max_batch=2, dtype="bf16")
+    eng.load_weights(W)
+    imgs = synth.make_images(cfg, 2, 32)
+    probs = eng.forward(imgs)
+    ref = oracle.forward(oracle_config(cfg), imgs, W)
+    assert float(np.abs(probs - ref).max()) <= BF16_PROB_TOL
+    assert (probs.argmax(1) == ref.argmax(1)).all()
     eng.close()

@@ -566,6 +566,166 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
     }
 }
 
+// bf16 MFMA attention for any sequence length: K (swizzled rows) and V (transposed) stream through LDS in
+// chunks of 224 keys with the online softmax of attention_f32_chunked_kernel.  ViT-L/16-384 (577 tokens).
+__global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(const bf16_t *__restrict__ qkv,
+                                                                             bf16_t *__restrict__ out, int tokens,
+                                                                             int heads) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[CKEYS * HD + HD * VT_LD];
+    bf16_t *const Ks = lds;
+    bf16_t *const Vt = lds + CKEYS * HD;
+
+    const int head = blockIdx.x, img = blockIdx.y;
+    const int D = heads * HD, ld = 3 * D;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bf16_t *base = qkv + (size_t)img * tokens * ld + head * HD;
+
+    const int q0 = (blockIdx.z * ATT_WAVES + wave) * 32;
+    const bool active = q0 < tokens;  // wave-uniform
+    bf16x8 qf[4];
+    {
+        int qrow = q0 + r;
+        qrow = qrow < tokens ? qrow : tokens - 1;
+        const bf16_t *qsrc = base + (size_t)qrow * ld + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qsrc + ks * 16);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[dt][v] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    constexpr float kScale = 0.125f * 1.4426950408889634f;
+    const int h4 = 4 * h, sw = (r >> 1) & 7;
+
+    const int nchunks = (tokens + CKEYS - 1) / CKEYS;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int key_base = ch * CKEYS;
+        const int ckeys = tokens - key_base < CKEYS ? tokens - key_base : CKEYS;
+        if (ch > 0) __syncthreads();
+        {
+            const int c8 = tid & 7;
+            constexpr int ROWS_PER_PASS = ATT_THREADS / 8;
+            constexpr int PASSES = (CKEYS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+            uint4 kreg[PASSES], vreg[PASSES];
+#pragma unroll
+            for (int it = 0; it < PASSES; ++it) {
+                const int row = (tid >> 3) + it * ROWS_PER_PASS;
+                const int srow = key_base + (row < ckeys ? row : ckeys - 1);
+                const bf16_t *src = base + (size_t)srow * ld + c8 * 8;
+                kreg[it] = *reinterpret_cast<const uint4 *>(src + D);
+                vreg[it] = *reinterpret_cast<const uint4 *>(src + 2 * D);
+            }
+#pragma unroll
+            for (int it = 0; it < PASSES; ++it) {
+                const int row = (tid >> 3) + it * ROWS_PER_PASS;
+                if (row < CKEYS) {
+                    const bool ok = row < ckeys;
+                    const uint4 zero = {0u, 0u, 0u, 0u};
+                    const uint4 kv = ok ? kreg[it] : zero, vv = ok ? vreg[it] : zero;
+                    *reinterpret_cast<uint4 *>(Ks + row * HD + ((c8 ^ ((row >> 1) & 7)) * 8)) = kv;
+                    const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        Vt[(c8 * 8 + 2 * q) * VT_LD + row] = (bf16_t)(w[q] & 0xffffu);
+                        Vt[(c8 * 8 + 2 * q + 1) * VT_LD + row] = (bf16_t)(w[q] >> 16);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        f32x16 st[CKT];
+#pragma unroll
+        for (int kt = 0; kt < CKT; ++kt) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) st[kt][v] = 0.0f;
+            if (kt * 32 < ckeys) {
+                const bf16_t *krow = Ks + (kt * 32 + r) * HD;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + h) ^ sw) & 7) * 8);
+                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kt], 0, 0, 0);
+                }
+            }
+        }
+        if (ckeys < CKEYS) {
+#pragma unroll
+            for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int kloc = kt * 32 + (v & 3) + 8 * (v >> 2);
+                    st[kt][v] = h4 < ckeys - kloc ? st[kt][v] : -INFINITY;
+                }
+        }
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, st[kt][v]);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kScale);
+        m_run = m_new;
+        const float mxs = -m_new * kScale;
+        float csum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
+                st[kt][v] = e;
+                csum += e;
+            }
+        l_run = l_run * alpha + csum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[dt][v] *= alpha;
+
+#pragma unroll
+        for (int kt = 0; kt < CKT; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (kt * 32 + 16 * s2 < ckeys) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][8 * s2 + j];
+                    const int key0 = kt * 32 + 16 * s2 + 4 * h;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const bf16_t *vrow = Vt + (dt * 32 + r) * VT_LD + key0;
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
+                        const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 8);
+                        const uint4 packed = {lo.x, lo.y, hi.x, hi.y};
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, packed), pf, o[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    if (active && q0 + r < tokens) {
+        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+        bf16_t *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w;
+                w[0] = o[dt][4 * g + 0] * inv;
+                w[1] = o[dt][4 * g + 1] * inv;
+                w[2] = o[dt][4 * g + 2] * inv;
+                w[3] = o[dt][4 * g + 3] * inv;
+                store4<bf16_t>(dst + dt * 32 + 8 * g, w);
+            }
+    }
+}
+
 template <int NKT>
 int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads) {
     hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads);
@@ -632,7 +792,12 @@ extern "C" int vithip_attention_bf16io(vithip_stream_t stream, const unsigned sh
             case 5: return launch_bf16<5>(s, qkv, out, n_images, tokens, heads);
             case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads);
             case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads);
-            default: break;
+            default: {
+                const int qblocks = ((tokens + 31) / 32 + ATT_WAVES - 1) / ATT_WAVES;
+                hipLaunchKernelGGL(attention_bf16_chunked_kernel, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s, qkv,
+                                   out, tokens, heads);
+                return static_cast<int>(hipGetLastError());
+            }
         }
     }
     return attention_dispatch<bf16_t>(s, qkv, out, n_images, tokens, heads);
