@@ -11,6 +11,8 @@ L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(B.CGemmBf16Args)]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 M = batch * 197
 SHAPES = {"qkv": (M, 2304, 768, 0), "outproj": (M, 768, 768, 2), "fc1": (M, 3072, 768, 1), "fc2": (M, 768, 3072, 2)}
+if len(sys.argv) > 2 and sys.argv[2] == "probe":  # timing-only builds on the qkv shape: 101 = no DMA in loop, 102 = DMA only
+    SHAPES = {"qkv": (M, 2304, 768, 0), "qkv_no_dma": (M, 2304, 768, 101), "qkv_dma_only": (M, 2304, 768, 102)}
 rng = np.random.default_rng(0)
 for name, (M_, N, K, epi) in SHAPES.items():
     a = rng.integers(0x3c00, 0x4000, size=(M_, K), dtype=np.uint16)  # bf16 bit patterns in [0.0078, 2)

@@ -54,7 +54,9 @@ struct Bf16Params {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int EPI>
+// DBG: timing-only probes (tools/gemm_bf16_probe.py): 1 = no LDS-DMA inside the K loop (MFMA + ds_read only),
+// 2 = no MFMA/ds_read inside the K loop (LDS-DMA stream only).  Results are wrong by construction.
+template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_nt_kernel(const Bf16Params p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
 
@@ -63,27 +65,37 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_nt_kernel(const Bf16Para
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 128 rows x 64 columns each
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    tile_coords(tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * TBN;
+    // Persistent walk: one workgroup per CU takes tiles first, first + nwg, ...; the first K step of the
+    // NEXT tile is fetched (LDS-DMA) before the epilogue of the current one, so the load latency that would
+    // open every tile hides under the stores.
+    const int total = p.tiles_m * p.tiles_n, nwg = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, nwg);
+    if (tile >= total) return;  // workgroup-uniform
+    int m0 = 0, n0 = 0;
 
     // ---- staging: wave w fills rows [32w, 32w+32) of the A tile and of the W tile, 4 DMA instructions
     // each (8 rows x 128 B per instruction).  Lane l lands at (row q*8 + l/8, chunk l%8) and therefore
     // fetches source chunk (l%8) ^ ((row>>1)&7) of that row.
     const char *a_src[4];
     const char *w_src[4];
+    auto set_tile = [&](int t) {
+        int tm, tn;
+        tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        m0 = tm * TBM;
+        n0 = tn * TBN;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = wave * 32 + q * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        int m = m0 + row;
-        m = m < p.M ? m : p.M - 1;
-        int n = n0 + row;
-        n = n < p.N ? n : p.N - 1;
-        a_src[q] = reinterpret_cast<const char *>(p.A + (size_t)m * p.lda) + chunk * 16;
-        w_src[q] = reinterpret_cast<const char *>(p.W + (size_t)n * p.ldw) + chunk * 16;
-    }
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 32 + q * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            int n = n0 + row;
+            n = n < p.N ? n : p.N - 1;
+            a_src[q] = reinterpret_cast<const char *>(p.A + (size_t)m * p.lda) + chunk * 16;
+            w_src[q] = reinterpret_cast<const char *>(p.W + (size_t)n * p.ldw) + chunk * 16;
+        }
+    };
+    set_tile(tile);
     auto stage = [&](int buf, int k0) {
         char *a_dst = lds + buf * STAGE_BYTES + wave * 32 * ROWB;
         char *w_dst = a_dst + TBM * ROWB;
@@ -108,113 +120,140 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_bf16_nt_kernel(const Bf16Para
     }
     const int sw = (r >> 1) & 7;  // every fragment row of this lane is r (mod 32): same swizzle key
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
-
     const int nk = p.K / TBK;
+    int par = 0;  // LDS stage holding K step 0 of the current tile
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * TBK);
-        const char *base = lds + cur * STAGE_BYTES;
+    for (;;) {
+        f32x16 acc[2][4];
 #pragma unroll
-        for (int ks = 0; ks < TBK / 16; ++ks) {
-            const int coff = (((2 * ks + h) ^ sw) & 7) * 16;
-            bf16x8 wf[2], af[4];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(base + w_off[j] + coff);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(base + a_off[i] + coff);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of the next stage has landed
-        __syncthreads();                                    // ... and everybody is done reading this one
-    }
-
-    // ---- epilogue: lane owns row m, register group g of accumulator (j, i) = columns nb .. nb+3 ------
-    // vmcnt counts stores: a load waited for between stores serialises them on the write latency (the
-    // lesson of the fp32 kernel).  So all 8 bias vectors are fetched up front, interior tiles run without
-    // a single branch, and residual rows are fetched four at a time before their four stores.
-    f32x4 b4[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
-            nb = nb + 4 <= p.N ? nb : p.N - 4;  // clamped address; such groups are never stored
-            b4[j][g] = *reinterpret_cast<const f32x4 *>(p.bias + nb);
-        }
-    auto finish = [&](float t) {
-        if constexpr (EPI == VITHIP_BF16_EPI_BF16_GELU) t = 0.5f * t * (1.0f + erf_fp32(t * 0.70710678118654752440f));
-        return t;
-    };
-    const bool interior = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);  // workgroup-uniform
-    if (interior) {
+                for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
+        // bias of this tile's columns, fetched now (drained by the wait below, used a whole tile later)
+        f32x4 b4[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
-                const size_t mrow = (size_t)(m0 + wm * 128 + r);
-                if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
-                    f32x4 res[4];
+                int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+                nb = nb + 4 <= p.N ? nb : p.N - 4;  // clamped address; such groups are never stored
+                b4[j][g] = *reinterpret_cast<const f32x4 *>(p.bias + nb);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = par ^ (kt & 1);
+            if (DBG != 1 && kt + 1 < nk) stage(cur ^ 1, (kt + 1) * TBK);
+            const char *base = lds + cur * STAGE_BYTES;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) res[i] = *reinterpret_cast<const f32x4 *>(p.R + (mrow + i * 32) * p.ldr + nb);
+            for (int ks = 0; ks < (DBG == 2 ? 0 : TBK / 16); ++ks) {
+                const int coff = (((2 * ks + h) ^ sw) & 7) * 16;
+                bf16x8 wf[2], af[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        f32x4 y;
+                for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(base + w_off[j] + coff);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) y[q] = acc[j][i][4 * g + q] + b4[j][g][q] + res[i][q];
-                        *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + (mrow + i * 32) * p.ldc + nb) = y;
-                    }
-                } else {
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(base + a_off[i] + coff);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        bf16x4 y;
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) y[q] = (__bf16)finish(acc[j][i][4 * g + q] + b4[j][g][q]);
-                        *reinterpret_cast<bf16x4 *>(static_cast<bf16_t *>(p.C) + (mrow + i * 32) * p.ldc + nb) = y;
+                    for (int i = 0; i < 4; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of the next stage has landed
+            __syncthreads();                                    // ... and everybody is done reading this one
+        }
+        par ^= (nk & 1) ^ 1;  // the stage NOT used by the last K step: free for the next tile's first step
+
+        // ---- epilogue through LDS --------------------------------------------------------------------
+        // In registers a lane owns one row and 4 consecutive columns per group, so direct stores would be
+        // 16-B (bf16) / 32-B (fp32) fragments scattered over 32 rows per instruction -- measured: the store
+        // phase cost as much as the whole K loop.  The tile is therefore transposed through the (now idle)
+        // LDS in row blocks and leaves as full 512-B / 1-KB row segments, 16 B per lane; the residual is read
+        // the same coalesced way.  Row pitches 520 B / 1040 B keep the block writes conflict-free.
+        auto finish = [&](float t) {
+            if constexpr (EPI == VITHIP_BF16_EPI_BF16_GELU) t = 0.5f * t * (1.0f + erf_fp32(t * 0.70710678118654752440f));
+            return t;
+        };
+        if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
+            constexpr int PITCH = TBN * 4 + 16;  // 1040 B
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {  // 64 rows per pass: waves wm == pass/2, accumulators i = 2*(pass&1), +1
+                if (wm == (pass >> 1)) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int i = 2 * (pass & 1) + ii;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                f32x4 y;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) y[q] = acc[j][i][4 * g + q] + b4[j][g][q];
+                                *reinterpret_cast<f32x4 *>(lds + (ii * 32 + r) * PITCH + (wn * 64 + j * 32 + 8 * g + 4 * h) * 4) = y;
+                            }
                     }
                 }
-            }
-    } else {
-        // edge tiles: per-row / per-group guards
+                __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + wm * 128 + i * 32 + r;
-                    if (m < p.M && nb + 4 <= p.N) {
-                        if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
-                            const f32x4 res = *reinterpret_cast<const f32x4 *>(p.R + (size_t)m * p.ldr + nb);
-                            f32x4 y;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) y[q] = acc[j][i][4 * g + q] + b4[j][g][q] + res[q];
-                            *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + (size_t)m * p.ldc + nb) = y;
-                        } else {
-                            bf16x4 y;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) y[q] = (__bf16)finish(acc[j][i][4 * g + q] + b4[j][g][q]);
-                            *reinterpret_cast<bf16x4 *>(static_cast<bf16_t *>(p.C) + (size_t)m * p.ldc + nb) = y;
-                        }
+                for (int it = 0; it < 8; ++it) {  // 64 rows x 64 chunks of 16 B over 512 threads
+                    const int c = tid + it * THREADS;
+                    const int row = c >> 6, col4 = (c & 63) * 4;
+                    const int m = m0 + pass * 64 + row, n = n0 + col4;
+                    if (m < p.M && n + 4 <= p.N) {
+                        const f32x4 y = *reinterpret_cast<const f32x4 *>(lds + row * PITCH + col4 * 4);
+                        const f32x4 res = *reinterpret_cast<const f32x4 *>(p.R + (size_t)m * p.ldr + n);
+                        *reinterpret_cast<f32x4 *>(static_cast<float *>(p.C) + (size_t)m * p.ldc + n) = y + res;
                     }
                 }
+                __syncthreads();
             }
+        } else {
+            constexpr int PITCH = TBN * 2 + 8;  // 520 B
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {  // 128 rows per pass: the waves with wm == pass
+                if (wm == pass) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                bf16x4 y;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) y[q] = (__bf16)finish(acc[j][i][4 * g + q] + b4[j][g][q]);
+                                *reinterpret_cast<bf16x4 *>(lds + (i * 32 + r) * PITCH + (wn * 64 + j * 32 + 8 * g + 4 * h) * 2) = y;
+                            }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {  // 128 rows x 32 chunks of 16 B over 512 threads
+                    const int c = tid + it * THREADS;
+                    const int row = c >> 5, col8 = (c & 31) * 8;
+                    const int m = m0 + pass * 128 + row, n = n0 + col8;
+                    if (m < p.M && n + 8 <= p.N) {
+                        const uint4 y = *reinterpret_cast<const uint4 *>(lds + row * PITCH + col8 * 2);
+                        *reinterpret_cast<uint4 *>(static_cast<bf16_t *>(p.C) + (size_t)m * p.ldc + n) = y;
+                    } else if (m < p.M && n < p.N) {  // ragged N (N % 8 != 0): element-wise tail
+                        for (int q = 0; q < 8 && n + q < p.N; ++q)
+                            static_cast<bf16_t *>(p.C)[(size_t)m * p.ldc + n + q] =
+                                *reinterpret_cast<const bf16_t *>(lds + row * PITCH + (col8 + q) * 2);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        const int next = tile + nwg;
+        const bool has_next = next < total;  // workgroup-uniform
+        if (has_next) {
+            set_tile(next);
+            stage(par, 0);
+        }
+        if (!has_next) break;
+        tile = next;
     }
 }
 
@@ -232,6 +271,7 @@ __global__ void f32_to_bf16_kernel(const float *__restrict__ src, bf16_t *__rest
 }
 
 bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
+int g_cus = 0;  // CU count, queried once
 
 }  // namespace
 
@@ -264,9 +304,17 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     p.tiles_m = (p.M + TBM - 1) / TBM;
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
-    const dim3 grid(p.tiles_m * p.tiles_n), block(THREADS);
+    if (g_cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return static_cast<int>(hipErrorInvalidDevice);
+    }
+    const int total = p.tiles_m * p.tiles_n;
+    const dim3 grid(total < g_cus ? total : g_cus), block(THREADS);  // one persistent workgroup per CU
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (a->epilogue) {
+        case 101: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 1>), grid, block, 0, s, p); break;
+        case 102: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 2>), grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16_GELU>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_F32_RESIDUAL>, grid, block, 0, s, p); break;
