@@ -34,6 +34,18 @@ void free_image_data(ImageData *images);
  * exit(EXIT_FAILURE) after perror() when the directory cannot be opened or memory runs out. */
 void load_weights(const char *directory, Network network[], int count);
 void free_weights(Network network[], int count);
+/*
+ * Packed weight cache: load_weights() opens 152 files and rounds 86.6 M values on
+ * every start.  vit_save_weight_cache() writes the already-rounded tensors of `network` into ONE file
+ * (header: magic "VITW", version, count, per-tensor element counts; then the raw fp32 data);
+ * vit_load_weight_cache() restores {data,size} for every entry from it with a single read.
+ * Both return 0 on success, -1 on any I/O or format error (the caller then falls back to load_weights()).
+ */
+int vit_save_weight_cache(const char *path, const Network network[], int count);
+int vit_load_weight_cache(const char *path, Network network[], int count);
+/* load_weights() through the cache: uses <directory>/vit_weights.cache when present and consistent with
+ * `count`, otherwise scans the directory as load_weights() does and (best effort) writes the cache. */
+void load_weights_cached(const char *directory, Network network[], int count);
 /* The loader's rounding on its own (Network.c:184-187). */
 void vit_round_weights(float *data, size_t count);
 

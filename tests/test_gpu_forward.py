@@ -181,3 +181,20 @@ def test_concurrent_lanes_give_identical_results(b16, lanes):
     finally:
         eng.set_lanes(1)
     assert np.array_equal(got, ref)
+
+
+def test_empty_and_invalid_inputs(b16):
+    """Empty input: the facade is a no-op for image[0].n == 0 (the reference's loop simply would not run,
+    ViT_opencl.c:802); the engine API rejects n <= 0 and NULL rows with an error code instead of crashing."""
+    import ctypes as C
+    eng, W = b16
+    L = B.lib()
+    img = np.zeros((3, 224, 224), np.float32)
+    one = (B.CImageData * 1)(B.CImageData(0, 3, 224, 224, img.ctypes.data_as(B.f32p)))
+    nets, keep = B.networks_from(W)
+    rows = (B.f32p * 1)()
+    L.initialize_hip()
+    L.ViT_hip(one, nets, rows)      # n == 0: returns without touching rows
+    L.Release_hip()
+    with pytest.raises(B.VitError, match="bad arguments"):
+        eng.forward(np.zeros((0, 3, 224, 224), np.float32))

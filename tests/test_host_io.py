@@ -62,6 +62,25 @@ def test_weight_loader_layout_rounding_and_gaps(tmp_path):
         assert np.array_equal(got[i], synth.round6(w).ravel()), f"tensor {i}"
 
 
+def test_packed_weight_cache_roundtrip(tmp_path):
+    cfg = synth.VIT_TINY
+    raw = [synth.uniform(9, i, int(np.prod(s)), -0.3, 0.3).reshape(s) for i, s in enumerate(cfg.weight_shapes())]
+    synth.write_weight_files(str(tmp_path), raw)
+    os.remove(tmp_path / "Weight_9_t9.bin")                      # gaps must survive the cache
+    first = B.load_weight_dir_cached(str(tmp_path), cfg.n_weights)     # scans the files, writes the cache
+    assert (tmp_path / "vit_weights.cache").exists()
+    for f in glob.glob(str(tmp_path / "Weight_*.bin")):
+        os.remove(f)                                                # now only the cache can answer
+    second = B.load_weight_dir_cached(str(tmp_path), cfg.n_weights)
+    for i, (a, b) in enumerate(zip(first, second)):
+        assert (a is None) == (b is None) == (i == 9)
+        if a is not None:
+            assert np.array_equal(a, b) and np.array_equal(a, synth.round6(raw[i]).ravel())
+    (tmp_path / "vit_weights.cache").write_bytes(b"garbage")       # a corrupt cache is ignored, not trusted
+    third = B.load_weight_dir_cached(str(tmp_path), cfg.n_weights)
+    assert all(w is None for w in third)
+
+
 def test_image_loader_roundtrip_and_failures(tmp_path):
     cfg = synth.VIT_TINY
     imgs = synth.make_images(cfg, 3, 5)

@@ -466,6 +466,18 @@ def load_weight_dir(directory: str, count: int):
     return out
 
 
+def load_weight_dir_cached(directory: str, count: int):
+    """load_weights_cached(): single-file cache next to the Weight_*.bin files."""
+    L = lib()
+    L.load_weights_cached.argtypes = [C.c_char_p, C.POINTER(CNetwork), C.c_int]
+    nets = (CNetwork * count)()
+    L.load_weights_cached(directory.encode(), nets, count)
+    out = [np.ctypeslib.as_array(nets[i].data, shape=(nets[i].size,)).copy() if nets[i].data else None
+           for i in range(count)]
+    L.free_weights(nets, count)
+    return out
+
+
 def round_weights(w: np.ndarray) -> np.ndarray:
     out = _as_f32(w).copy()
     lib().vit_round_weights(out.ctypes.data_as(f32p), out.size)

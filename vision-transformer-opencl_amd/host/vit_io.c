@@ -141,6 +141,68 @@ void free_weights(Network network[], int count) {
     }
 }
 
+/* ---- packed weight cache ------------------------------------------------------------------- */
+
+#define VITW_MAGIC 0x57544956u /* "VITW" little endian */
+#define VITW_VERSION 1u
+
+int vit_save_weight_cache(const char *path, const Network network[], int count) {
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return -1;
+    uint32_t hdr[3] = {VITW_MAGIC, VITW_VERSION, (uint32_t)count};
+    int ok = fwrite(hdr, sizeof(uint32_t), 3, fp) == 3;
+    for (int i = 0; ok && i < count; ++i) {
+        const uint64_t n = network[i].data ? (uint64_t)network[i].size : 0;
+        ok = fwrite(&n, sizeof(n), 1, fp) == 1;
+    }
+    for (int i = 0; ok && i < count; ++i)
+        if (network[i].data && network[i].size) ok = fwrite(network[i].data, sizeof(float), network[i].size, fp) == network[i].size;
+    if (fclose(fp) != 0) ok = 0;
+    if (!ok) remove(path);
+    return ok ? 0 : -1;
+}
+
+int vit_load_weight_cache(const char *path, Network network[], int count) {
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return -1;
+    uint32_t hdr[3];
+    if (fread(hdr, sizeof(uint32_t), 3, fp) != 3 || hdr[0] != VITW_MAGIC || hdr[1] != VITW_VERSION || hdr[2] != (uint32_t)count) {
+        fclose(fp);
+        return -1;
+    }
+    uint64_t *sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(count > 0 ? count : 1));
+    if (!sizes || fread(sizes, sizeof(uint64_t), (size_t)count, fp) != (size_t)count) {
+        free(sizes);
+        fclose(fp);
+        return -1;
+    }
+    for (int i = 0; i < count; ++i) { network[i].data = NULL; network[i].size = 0; }
+    int ok = 1;
+    for (int i = 0; ok && i < count; ++i) {
+        if (!sizes[i]) continue;
+        float *buf = (float *)malloc((size_t)sizes[i] * sizeof(float));
+        if (!buf || fread(buf, sizeof(float), (size_t)sizes[i], fp) != (size_t)sizes[i]) {
+            free(buf);
+            ok = 0;
+            break;
+        }
+        network[i].data = buf;
+        network[i].size = (size_t)sizes[i];
+    }
+    free(sizes);
+    fclose(fp);
+    if (!ok) free_weights(network, count);
+    return ok ? 0 : -1;
+}
+
+void load_weights_cached(const char *directory, Network network[], int count) {
+    char path[1024];
+    snprintf(path, sizeof(path), "%s/vit_weights.cache", directory);
+    if (vit_load_weight_cache(path, network, count) == 0) return;
+    load_weights(directory, network, count);
+    (void)vit_save_weight_cache(path, network, count); /* best effort: a read-only directory just stays uncached */
+}
+
 /* ---- results ------------------------------------------------------------------------------- */
 
 int vit_argmax(const float *probs, int classes) {

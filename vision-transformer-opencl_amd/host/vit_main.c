@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     if (synthetic) {
         if (vit_synth_weights(&cfg, seed, network, nw)) return 1;
     } else {
-        load_weights(weight_dir, network, nw); /* Main.c:30 */
+        load_weights_cached(weight_dir, network, nw); /* Main.c:30, through the packed cache */
     }
 
     int n = images[0].n;
