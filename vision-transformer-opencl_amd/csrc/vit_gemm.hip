@@ -83,17 +83,25 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
     const int ld_kc = (tid % (BK / 4)) * 4;     // float offset inside the K step
     const float *a_src[A_CHUNKS];
     const float *b_src[B_CHUNKS];
+    // Dense operands are fetched with buffer loads (SGPR descriptor + 32-bit per-thread byte offset + SGPR
+    // K offset): stepping through K then costs no vector instruction (fp32 VALU time is matrix-pipe time
+    // on gfx950).  The launcher keeps operands below 2 GB.
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.W), 0, 0x7fffffff, 0x00020000);
+    int a_boff[A_CHUNKS], b_boff[B_CHUNKS];
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
         int m = m0 + ld_row + i * ROWS_PER_PASS;
         m = m < p.M ? m : p.M - 1;
         if constexpr (AMODE == A_DENSE) {
             a_src[i] = p.A + (size_t)m * p.lda + ld_kc;
+            a_boff[i] = (m * p.lda + ld_kc) * 4;
         } else {
             // row m = (image, patch); k = (ic, kh, kw): resolved per K step in load_a()
             const int im = m / p.patches, pp = m - im * p.patches;
             const int oh = pp / p.grid, ow = pp - oh * p.grid;
             a_src[i] = p.A + ((size_t)im * p.chans * p.img + (size_t)oh * p.patch) * p.img + ow * p.patch;
+            a_boff[i] = 0;
         }
     }
 #pragma unroll
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
         int n = n0 + ld_row + i * ROWS_PER_PASS;
         n = n < p.N ? n : p.N - 1;
         b_src[i] = p.W + (size_t)n * p.ldw + ld_kc;
+        b_boff[i] = (n * p.ldw + ld_kc) * 4;
     }
 
     f32x4 a_stage[A_CHUNKS], b_stage[B_CHUNKS];
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             if constexpr (AMODE == A_DENSE) {
-                a_stage[i] = *reinterpret_cast<const f32x4 *>(a_src[i] + k0);
+                a_stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_boff[i], k0 * 4, 0));
             } else {
                 const int k = k0 + ld_kc;
                 const int pp2 = p.patch * p.patch;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
             }
         }
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) b_stage[i] = *reinterpret_cast<const f32x4 *>(b_src[i] + k0);
+        for (int i = 0; i < B_CHUNKS; ++i) b_stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_boff[i], k0 * 4, 0));
     };
     auto store_lds = [&](int buf) {
         float *As = As0 + buf * BM * LDS_LD;
@@ -176,12 +185,12 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
             if (q < A_CHUNKS) {
                 float *As = As0 + buf * BM * LDS_LD;
                 *reinterpret_cast<f32x4 *>(As + (ld_row + q * ROWS_PER_PASS) * LDS_LD + ld_kc) = a_stage[q];
-                a_stage[q] = *reinterpret_cast<const f32x4 *>(a_src[q] + k0);
+                a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_boff[q], k0 * 4, 0));
             } else {
                 const int qb = q - A_CHUNKS;
                 float *Bs = Bs0 + buf * BN * LDS_LD;
                 *reinterpret_cast<f32x4 *>(Bs + (ld_row + qb * ROWS_PER_PASS) * LDS_LD + ld_kc) = b_stage[qb];
-                b_stage[qb] = *reinterpret_cast<const f32x4 *>(b_src[qb] + k0);
+                b_stage[qb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_boff[qb], k0 * 4, 0));
             }
         };
         static_assert(AMODE == A_DENSE, "pipelined loop: dense A only");
@@ -406,6 +415,8 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     if (a->lda % 4 || a->ldw % 4 || a->lda < a->K || a->ldw < a->K || a->ldc < a->N)
         return static_cast<int>(hipErrorInvalidValue);
     if (!aligned16(a->A) || !aligned16(a->W)) return static_cast<int>(hipErrorInvalidValue);
+    if ((size_t)a->M * a->lda * 4 >= 0x7fffffffull || (size_t)a->N * a->ldw * 4 >= 0x7fffffffull)
+        return static_cast<int>(hipErrorInvalidValue);  // 32-bit buffer offsets: split the batch (vit_engine does)
     if (a->epilogue == VITHIP_EPI_BIAS_RESIDUAL && (!a->residual || a->ldr < a->N))
         return static_cast<int>(hipErrorInvalidValue);
     GemmParams p{};

@@ -57,8 +57,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
 
     const int ld_row = tid / (PBK / 4);
     const int ld_kc = (tid % (PBK / 4)) * 4;
-    const float *a_src[A_CHUNKS];
-    const float *b_src[B_CHUNKS];
+    // Staging loads are buffer loads: SGPR descriptor + per-thread 32-bit byte offset + SGPR K offset, so
+    // stepping through K costs no vector instruction (a 64-bit v_lshl_add per load otherwise -- and fp32
+    // VALU time comes out of the matrix pipe's).  Offsets fit 32 bits: the largest operand (fc2's A at
+    // batch 256) is 620 MB; the launcher refuses operands >= 2 GB for this kernel.
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.W), 0, 0x7fffffff, 0x00020000);
+    int a_src[A_CHUNKS];  // byte offsets
+    int b_src[B_CHUNKS];
     f32x4 a_stage[A_CHUNKS], b_stage[B_CHUNKS];
 
     auto set_sources = [&](int tile) {
@@ -68,13 +74,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         for (int i = 0; i < A_CHUNKS; ++i) {
             int m = tm * BM + ld_row + i * ROWS_PER_PASS;
             m = m < p.M ? m : p.M - 1;
-            a_src[i] = p.A + (size_t)m * p.lda + ld_kc;
+            a_src[i] = (m * p.lda + ld_kc) * 4;
         }
 #pragma unroll
         for (int i = 0; i < B_CHUNKS; ++i) {
             int n = tn * BN + ld_row + i * ROWS_PER_PASS;
             n = n < p.N ? n : p.N - 1;
-            b_src[i] = p.W + (size_t)n * p.ldw + ld_kc;
+            b_src[i] = (n * p.ldw + ld_kc) * 4;
         }
     };
     auto load_bias = [&](int n0, float (&dst)[TN]) {
@@ -99,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     auto load_step = [&]() {
         const int k0 = k_l * PBK;
 #pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) a_stage[i] = *reinterpret_cast<const f32x4 *>(a_src[i] + k0);
+        for (int i = 0; i < A_CHUNKS; ++i) a_stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_src[i], k0 * 4, 0));
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) b_stage[i] = *reinterpret_cast<const f32x4 *>(b_src[i] + k0);
+        for (int i = 0; i < B_CHUNKS; ++i) b_stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_src[i], k0 * 4, 0));
     };
     auto store_step = [&](int buf) {
         float *As = As0 + buf * BM * PLD, *Bs = Bs0 + buf * BN * PLD;
@@ -117,12 +123,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         if (q < A_CHUNKS) {
             float *As = As0 + buf * BM * PLD;
             *reinterpret_cast<f32x4 *>(As + (ld_row + q * ROWS_PER_PASS) * PLD + ld_kc) = a_stage[q];
-            a_stage[q] = *reinterpret_cast<const f32x4 *>(a_src[q] + k0);
+            a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_src[q], k0 * 4, 0));
         } else {
             const int qb = q - A_CHUNKS;
             float *Bs = Bs0 + buf * BN * PLD;
             *reinterpret_cast<f32x4 *>(Bs + (ld_row + qb * ROWS_PER_PASS) * PLD + ld_kc) = b_stage[qb];
-            b_stage[qb] = *reinterpret_cast<const f32x4 *>(b_src[qb] + k0);
+            b_stage[qb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_src[qb], k0 * 4, 0));
         }
     };
 
