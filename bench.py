@@ -39,6 +39,21 @@ STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it
 }
 
 
+def pmc_traffic(kernel, dtype, batch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01/README.md: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, summarised by tools/pmc_summary.py).
+    Not collected live: counters need the profiler.  None when the passes do not cover this configuration."""
+    path = os.path.join(ROOT, "profiles", "r01", f"hbm_traffic_pmc_{dtype}.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    if rec.get("batch") != batch:
+        return None
+    return rec["kernels"].get(kernel)
+
+
 def stage_macs(cfg, batch):
     T, D, H = cfg.tokens, cfg.embed_dim, cfg.hidden_dim
     M = batch * T
@@ -58,6 +73,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (metric config: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-forward-per-core aggregate CPU figure")
+    ap.add_argument("--cpu-all-cores", type=int, default=16,
+                    help="cap on concurrent single-threaded CPU forwards for cpu_baseline.all_cores (a 1-GPU box's CPU share is 16)")
     ap.add_argument("--lanes", type=int, default=2,
                     help="concurrent sub-batches per step (engine option; 1 = every kernel alone on the GPU)")
     ap.add_argument("--kernel-steps", type=int, default=3,
@@ -187,7 +205,7 @@ def main() -> None:
     gemm_flop = sum(v["flop"] for k, v in per_kernel.items() if k.startswith("gemm"))
     roofline = {
         "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
-        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom_name, args.dtype, B),
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
         "flop_per_launch": dom["flop"] / max(dom["launches"], 1),
         "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
@@ -216,6 +234,21 @@ def main() -> None:
                   "tolerance": 1e-4 if args.dtype == "f32" else 2e-2}
         cpu = {"value": round(1.0 / cpu_dt, 5), "unit": "images/sec", "cores": args.cpu_threads, "kind": "port",
                "sample": f"image 0 of the batch (1 of {B}), {cpu_dt:.2f} s, oracle/vit_cpu_ref.c gcc -O2 -ffp-contract=off"}
+        if args.cpu_threads == 1 and not args.no_cpu_all_cores:
+            # the reference is single-threaded, so the honest "all cores" figure is one independent
+            # single-threaded forward per core, run concurrently (ctypes releases the GIL; the oracle has no shared state)
+            import threading
+            ncore = min(len(os.sched_getaffinity(0)), args.cpu_all_cores)
+            ths = [threading.Thread(target=po.forward_image, args=(ocfg, host_imgs[i % n_distinct], weights))
+                   for i in range(ncore)]
+            t2 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            all_dt = time.perf_counter() - t2
+            cpu["all_cores"] = {"value": round(ncore / all_dt, 4), "unit": "images/sec", "cores": ncore,
+                                "sample": f"{ncore} concurrent single-threaded forwards (one image each), {all_dt:.2f} s"}
 
     if rank == 0:
         info = binding.device_info(local_rank)

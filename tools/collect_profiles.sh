@@ -1,0 +1,40 @@
+#!/bin/bash
+# Re-creates profiles/<round>/ on a GPU box:  gpurun -- 'bash tools/collect_profiles.sh r01'
+# One rocprofv3 command per file; PMC passes are separate runs with --kernel-trace only (no --stats, no
+# sys/hip traces); the program comes directly after `--` (no env/bash hop).  Results land in
+# gpurun_out/profiles/<round>/ -- copy them into profiles/<round>/ and commit.
+set -eo pipefail
+R=${1:-r01}
+OUT=gpurun_out/profiles/$R
+W=gpurun_out/prof_work
+rm -rf "$W" "$OUT"; mkdir -p "$W" "$OUT"
+export TMPDIR=/tmp
+
+stats() {  # name, bench args...
+    local name=$1; shift
+    timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/$name" -- \
+        python3 bench.py --no-cpu-baseline "$@" > "$OUT/bench_$name.json" 2> "$W/$name.err"
+    cp "$(find "$W/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_$name.csv"
+    echo "stats $name done"
+}
+pmc() {  # name, counter, bench args...
+    local name=$1 ctr=$2; shift 2
+    timeout -k 10 500 rocprofv3 --pmc "$ctr" --kernel-trace --output-format csv -d "$W/$name" -- \
+        python3 bench.py --no-cpu-baseline --lanes 1 --steps 2 --warmup 1 "$@" > /dev/null 2> "$W/$name.err"
+    echo "pmc $name done"
+}
+
+stats f32_lanes1 --lanes 1
+stats f32_default
+pmc f32_fetch FETCH_SIZE
+pmc f32_write WRITE_SIZE
+python3 tools/pmc_summary.py "$W/f32_fetch" "$W/f32_write" "$OUT/hbm_traffic_pmc_f32" 256
+if [ "$2" != "f32only" ]; then
+    stats bf16_batch2048 --dtype bf16 --batch 2048 --steps 5 --warmup 2
+    pmc bf16_fetch FETCH_SIZE --dtype bf16 --batch 2048
+    pmc bf16_write WRITE_SIZE --dtype bf16 --batch 2048
+    python3 tools/pmc_summary.py "$W/bf16_fetch" "$W/bf16_write" "$OUT/hbm_traffic_pmc_bf16" 2048
+fi
+# the unprofiled headline run, with the CPU baseline and the parity block
+timeout -k 10 500 python3 bench.py > "$OUT/bench_f32_default_unprofiled.json" 2> "$W/unprofiled.err"
+echo "collect_profiles: done -> $OUT"
