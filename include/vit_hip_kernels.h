@@ -118,6 +118,10 @@ typedef struct {
 } vithip_gemm_bf16_args;
 /* C = epilogue(A . W^T + bias) on v_mfma_f32_32x32x16_bf16, fp32 accumulate. */
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
+/* tuning/testing: 0 auto (default), 1 two-stage kernel (vit_gemm_bf16.hip), 2 ping-pong kernel (vit_gemm_bf16_pp.hip) */
+int vithip_gemm_bf16_set_variant(int variant);
+/* probe only: variant 3 = ping-pong kernel with s_memtime stamps (8 waves x 32 u64 of workgroup 0) written to buf */
+int vithip_gemm_bf16_set_debug_buffer(void *buf);
 /* LayerNorm with fp32 statistics and a bf16 store; attention reading bf16 Q/K/V and writing bf16
  * (K/V widened to fp32 in LDS, fp32 MFMA and softmax as vithip_attention_f32). */
 int vithip_layernorm_f32_bf16out(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *y, size_t ldy,

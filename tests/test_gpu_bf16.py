@@ -23,7 +23,15 @@ def test_f32_to_bf16_matches_round_to_nearest_even():
     assert np.array_equal(B.f32_to_bf16_device(x), B.to_bf16_bits(x))
 
 
-def test_gemm_bf16_identity_asymmetric_exact():
+@pytest.fixture(params=[1, 2], ids=["two-stage", "ping-pong"])
+def variant(request):
+    """Both bf16 GEMM kernels behind vithip_gemm_bf16 (0 = auto picks ping-pong whenever K >= 128)."""
+    B.gemm_bf16_set_variant(request.param)
+    yield request.param
+    B.gemm_bf16_set_variant(0)
+
+
+def test_gemm_bf16_identity_asymmetric_exact(variant):
     K = 256
     A = B.to_bf16_bits(np.eye(K, dtype=np.float32))
     Wf = B.from_bf16_bits(B.to_bf16_bits(u(1, (256, K), 1.0)))      # values exactly representable in bf16
@@ -33,7 +41,9 @@ def test_gemm_bf16_identity_asymmetric_exact():
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 768, 768), (197, 2304, 768), (300, 100, 64), (1000, 768, 3072), (5, 12, 128)])
-def test_gemm_bf16_residual_fp32_out(oracle, M, N, K):
+def test_gemm_bf16_residual_fp32_out(oracle, variant, M, N, K):
+    if variant == 2 and K < 128:
+        pytest.skip("ping-pong kernel needs two K steps; auto mode uses the two-stage kernel here")
     Ab, Wb = B.to_bf16_bits(u(2, (M, K), 1.0)), B.to_bf16_bits(u(3, (N, K), 0.05))
     b, R = u(4, (N,), 0.1), u(5, (M, N), 2.0)
     ref = R + oracle.linear(B.from_bf16_bits(Ab), B.from_bf16_bits(Wb), b)
@@ -42,7 +52,7 @@ def test_gemm_bf16_residual_fp32_out(oracle, M, N, K):
 
 
 @pytest.mark.parametrize("epi", [B.BF16_EPI_BF16, B.BF16_EPI_BF16_GELU])
-def test_gemm_bf16_bf16_out(oracle, epi):
+def test_gemm_bf16_bf16_out(oracle, variant, epi):
     M, N, K = 515, 3072, 768
     Ab, Wb, b = B.to_bf16_bits(u(6, (M, K), 1.0)), B.to_bf16_bits(u(7, (N, K), 0.08)), u(8, (N,), 0.1)
     ref = oracle.linear(B.from_bf16_bits(Ab), B.from_bf16_bits(Wb), b)
@@ -51,6 +61,27 @@ def test_gemm_bf16_bf16_out(oracle, epi):
     got = B.from_bf16_bits(B.gemm_bf16(Ab, Wb, b, epilogue=epi))
     err = np.abs(got - ref)
     assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), float(err.max())       # one bf16 rounding of the result
+
+
+@pytest.mark.parametrize("epi", [B.BF16_EPI_BF16, B.BF16_EPI_BF16_GELU, B.BF16_EPI_F32_RESIDUAL])
+@pytest.mark.parametrize("M,N,K", [(256 * 37 + 19, 2048 + 4, 192), (256 * 80, 1024, 128), (9000, 768, 448)])
+def test_gemm_bf16_persistent_many_tiles(variant, epi, M, N, K):
+    """More tiles than workgroups (the persistent loop crosses tile boundaries with the load pipeline running),
+    odd and even K-step counts, ragged last tile row and a ragged (N % 8 == 4) last tile column.  Too large for
+    the scalar oracle, so the reference is a float64 matmul of the same bf16-exact operands."""
+    Ab, Wb, b = B.to_bf16_bits(u(9, (M, K), 1.0)), B.to_bf16_bits(u(10, (N, K), 0.08)), u(11, (N,), 0.1)
+    ref = B.from_bf16_bits(Ab).astype(np.float64) @ B.from_bf16_bits(Wb).astype(np.float64).T + b
+    if epi == B.BF16_EPI_F32_RESIDUAL:
+        R = u(12, (M, N), 2.0)
+        got = B.gemm_bf16(Ab, Wb, b, residual=R, epilogue=epi)
+        assert float(np.abs(got - (ref + R)).max()) <= 2e-5 * float(np.abs(ref + R).max())
+        return
+    if epi == B.BF16_EPI_BF16_GELU:
+        from scipy.special import erf
+        ref = 0.5 * ref * (1.0 + erf(ref / np.sqrt(2.0)))
+    got = B.from_bf16_bits(B.gemm_bf16(Ab, Wb, b, epilogue=epi))
+    err = np.abs(got - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), float(err.max())
 
 
 def test_layernorm_bf16_out(oracle):

@@ -23,7 +23,12 @@ for name, (M_, N, K, epi) in SHAPES.items():
     out_f32 = epi == 2
     dC = B.DeviceArray((M_, N), np.float32 if out_f32 else np.uint16)
     args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if out_f32 else None, N, dC.ptr, N, M_, N, K, epi)
-    ms = [timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=3, warm=1) for _ in range(3)]
-    print(json.dumps({name: {"ms": [round(m, 3) for m in ms], "tflops": round(2.0 * M_ * N * K / (min(ms) * 1e-3) / 1e12, 1)}}))
+    res = {}
+    for variant in ((1,) if epi > 2 else (1, 2, 1, 2)):  # interleaved A/B in one process (clocks differ per device/run)
+        B.gemm_bf16_set_variant(variant)
+        ms = [timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=3, warm=1) for _ in range(3)]
+        res.setdefault("two-stage" if variant == 1 else "ping-pong", []).append(round(2.0 * M_ * N * K / (min(ms) * 1e-3) / 1e12, 1))
+    B.gemm_bf16_set_variant(0)
+    print(json.dumps({name: {"tflops": res}}))
     for d in (dA, dW, db, dC):
         d.free()

@@ -260,6 +260,11 @@ def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16) -> np
     return dC.numpy()
 
 
+def gemm_bf16_set_variant(variant: int) -> None:
+    """0 auto, 1 two-stage kernel, 2 ping-pong kernel (fails for K < 128)."""
+    hip_check(lib().vithip_gemm_bf16_set_variant(int(variant)), "vithip_gemm_bf16_set_variant")
+
+
 def layernorm_bf16out(x, gamma, beta) -> np.ndarray:
     """vithip_layernorm_f32_bf16out -> bf16 bits."""
     x = _as_f32(x)

@@ -40,16 +40,7 @@ constexpr int ROWB = TBK * 2;                      // 128 bytes per LDS row
 constexpr int STAGE_BYTES = (TBM + TBN) * ROWB;    // 64 KB
 constexpr int THREADS = 512;
 
-struct Bf16Params {
-    const bf16_t *A;
-    const bf16_t *W;
-    const float *bias;
-    const float *R;
-    void *C;
-    int lda, ldw, ldr, ldc;
-    int M, N, K;
-    int tiles_m, tiles_n, group_m;
-};
+using vitgemm::Bf16Params;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -271,7 +262,9 @@ __global__ void f32_to_bf16_kernel(const float *__restrict__ src, bf16_t *__rest
 }
 
 bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
-int g_cus = 0;  // CU count, queried once
+int g_cus = 0;      // CU count, queried once
+int g_variant = 0;  // 0 auto (ping-pong kernel when its preconditions hold), 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong
+unsigned long long *g_dbg = nullptr;
 
 }  // namespace
 
@@ -286,6 +279,17 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, n4);
     return static_cast<int>(hipGetLastError());
+}
+
+int vithip_gemm_bf16_set_variant(int variant) {
+    if (variant < 0 || variant > 3) return static_cast<int>(hipErrorInvalidValue);
+    g_variant = variant;
+    return 0;
+}
+
+int vithip_gemm_bf16_set_debug_buffer(void *buf) {
+    g_dbg = static_cast<unsigned long long *>(buf);
+    return 0;
 }
 
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
@@ -312,6 +316,17 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     const int total = p.tiles_m * p.tiles_n;
     const dim3 grid(total < g_cus ? total : g_cus), block(THREADS);  // one persistent workgroup per CU
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // ping-pong kernel: needs two K steps per tile (its bias slot is recycled every second tile) and
+    // operands addressable through 32-bit buffer offsets inside one tile (always true: 256 rows)
+    const bool pp_ok = p.K >= 2 * TBK && a->epilogue <= VITHIP_BF16_EPI_F32_RESIDUAL &&
+                       (size_t)p.lda * 2 * 256 < (1u << 31) && (size_t)p.ldw * 2 * 256 < (1u << 31);
+    if (g_variant >= 2 && !pp_ok) return static_cast<int>(hipErrorInvalidValue);
+    if (g_variant == 3) {
+        if (!g_dbg) return static_cast<int>(hipErrorInvalidValue);
+        p.dbg = g_dbg;
+        return vitgemm::launch_gemm_bf16_pp(s, p, 100 + a->epilogue, g_cus);
+    }
+    if (g_variant != 1 && pp_ok) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);
     switch (a->epilogue) {
         case 101: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 1>), grid, block, 0, s, p); break;
         case 102: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 2>), grid, block, 0, s, p); break;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "vit_hip_kernels.h"
 
 namespace vitgemm {
@@ -208,5 +210,19 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
         }
     }
 }
+
+// ---- bf16 GEMM (vit_gemm_bf16.hip: launcher + two-stage kernel; vit_gemm_bf16_pp.hip: ping-pong kernel)
+struct Bf16Params {
+    const unsigned short *A;
+    const unsigned short *W;
+    const float *bias;
+    const float *R;
+    void *C;
+    int lda, ldw, ldr, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n, group_m;
+    unsigned long long *dbg;  // stamped probe build only
+};
+int launch_gemm_bf16_pp(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);
 
 }  // namespace vitgemm
