@@ -120,6 +120,11 @@ typedef struct {
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
 /* tuning/testing: 0 auto (default), 1 two-stage kernel (vit_gemm_bf16.hip), 2 ping-pong kernel (vit_gemm_bf16_pp.hip) */
 int vithip_gemm_bf16_set_variant(int variant);
+/* tuning: start-up skew between the persistent workgroups of the ping-pong kernel, units of 512 cycles per
+ * position inside the XCD (0..64) */
+int vithip_gemm_bf16_set_stagger(int units);
+/* probe only: cap the number of persistent workgroups of the event-log build (variant 4) */
+int vithip_gemm_bf16_set_max_workgroups(int n);
 /* probe only: variant 3 = ping-pong kernel with s_memtime stamps (8 waves x 32 u64 of workgroup 0) written to buf */
 int vithip_gemm_bf16_set_debug_buffer(void *buf);
 /* LayerNorm with fp32 statistics and a bf16 store; attention reading bf16 Q/K/V and writing bf16
@@ -137,6 +142,9 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
  * (4096 flop each).  Used by tools/gemm_probe.py to read the sustained matrix clock. */
 int vithip_probe_mfma_f32(vithip_stream_t stream, float *out, int blocks, int threads, int iters);
 /* Waves 0-3 of every 512-thread block issue iters*32 MFMAs, waves 4-7 valu_iters*64 independent v_fma_f32. */
+/* Store-path probe (tools/store_probe.py): per wave `iters` 16-B-per-lane stores; mode 0 = 1 KB contiguous, 1 = 16 rows x
+ * 64 B, 2 = 8 rows x 128 B at row stride `stride` bytes; cycles[2*wave] = issue span, [2*wave+1] = until complete. */
+int vithip_probe_store(vithip_stream_t stream, void *out, int blocks, int threads, int iters, int mode, size_t stride, void *cycles);
 int vithip_probe_mfma_vs_valu(vithip_stream_t stream, float *out, int blocks, int iters, int valu_iters);
 
 /*

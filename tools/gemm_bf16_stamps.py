@@ -40,4 +40,5 @@ for w in range(8):
     for p in range(4):
         t0 = r[0] if p == 0 else r[5 * (p - 1) + 4]
         cells.append(f"{d(r[5*p+1], t0):4d} {d(r[5*p+2], r[5*p+1]):5d} {d(r[5*p+3], r[5*p+2]):5d} {d(r[5*p+4], r[5*p+3]):5d} ")
-    print(f"{w:4d}  " + "  ".join(cells) + f"  | {d(r[19], r[0]):5d}  {d(r[21], r[20]):9d}  {d(r[22], r[21]):8d}  {d(r[23], r[20]):7d}")
+    print(f"{w:4d}  " + "  ".join(cells) + f"  | {d(r[19], r[0]):5d}  {d(r[21], r[20]):9d}  {d(r[22], r[21]):8d}  {d(r[23], r[20]):7d}"
+          f"  | L0: reads {d(r[24], r[0])} dma {d(r[25], r[24])} wait {d(r[1], r[25])}  L3: reads {d(r[26], r[14])} dma {d(r[27], r[26])} wait {d(r[16], r[27])}")

@@ -265,6 +265,8 @@ bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) ==
 int g_cus = 0;      // CU count, queried once
 int g_variant = 0;  // 0 auto (ping-pong kernel when its preconditions hold), 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong
 unsigned long long *g_dbg = nullptr;
+int g_stagger = 0;
+int g_max_wgs = 0;  // probe: cap on persistent workgroups (0 = one per CU)
 
 }  // namespace
 
@@ -282,8 +284,19 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
 }
 
 int vithip_gemm_bf16_set_variant(int variant) {
-    if (variant < 0 || variant > 3) return static_cast<int>(hipErrorInvalidValue);
+    if (variant < 0 || variant > 4) return static_cast<int>(hipErrorInvalidValue);
     g_variant = variant;
+    return 0;
+}
+
+int vithip_gemm_bf16_set_stagger(int units) {
+    if (units < 0 || units > 64) return static_cast<int>(hipErrorInvalidValue);
+    g_stagger = units;
+    return 0;
+}
+
+int vithip_gemm_bf16_set_max_workgroups(int n) {
+    g_max_wgs = n < 0 ? 0 : n;
     return 0;
 }
 
@@ -308,6 +321,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     p.tiles_m = (p.M + TBM - 1) / TBM;
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
+    p.stagger = g_stagger;
     if (g_cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -318,6 +332,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     // ping-pong kernel: needs two K steps per tile (its bias slot is recycled every second tile) and
     // operands addressable through 32-bit buffer offsets inside one tile (always true: 256 rows)
+    if (a->epilogue >= 201 && a->epilogue <= 204) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);  // timing probes
     const bool pp_ok = p.K >= 2 * TBK && a->epilogue <= VITHIP_BF16_EPI_F32_RESIDUAL &&
                        (size_t)p.lda * 2 * 256 < (1u << 31) && (size_t)p.ldw * 2 * 256 < (1u << 31);
     if (g_variant >= 2 && !pp_ok) return static_cast<int>(hipErrorInvalidValue);
@@ -325,6 +340,11 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
         if (!g_dbg) return static_cast<int>(hipErrorInvalidValue);
         p.dbg = g_dbg;
         return vitgemm::launch_gemm_bf16_pp(s, p, 100 + a->epilogue, g_cus);
+    }
+    if (g_variant == 4) {  // event-log build (bf16 and fp32-residual epilogues)
+        if (!g_dbg || a->epilogue == VITHIP_BF16_EPI_BF16_GELU) return static_cast<int>(hipErrorInvalidValue);
+        p.dbg = g_dbg;
+        return vitgemm::launch_gemm_bf16_pp(s, p, 300 + a->epilogue, g_max_wgs ? g_max_wgs : g_cus);
     }
     if (g_variant != 1 && pp_ok) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);
     switch (a->epilogue) {

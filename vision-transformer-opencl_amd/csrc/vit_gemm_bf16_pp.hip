@@ -48,10 +48,9 @@ constexpr int PBM = 256, PBN = 256, PBK = 64;
 constexpr int PTHREADS = 512;
 constexpr int SLOT = 128 * 128;               // one half-tile: 128 rows x 64 bf16
 constexpr int RING = 8 * SLOT;                // 128 KB
-constexpr int SCR_PITCH = 144;                // bytes per scratch row (16 rows x 64 bf16 + pad)
-constexpr int SCR_WAVE = 16 * SCR_PITCH;      // 2304 B per wave
-constexpr int BIAS_OFF = RING + 8 * SCR_WAVE; // two 1-KB bias slots (tile parity)
-constexpr int LDS_BYTES = BIAS_OFF + 2 * 1024;
+constexpr int BIAS_OFF = RING;                // two 1-KB bias slots (tile parity)
+constexpr int SCRATCH = RING + 2 * 1024;      // 8 x 2 KB: first epilogue transpose buffer of every wave
+constexpr int LDS_BYTES = SCRATCH + 8 * 2048;
 
 #define PP_BARRIER()                            \
     do {                                        \
@@ -66,26 +65,53 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 
 // STAMP: timing-only instrumentation for tools/gemm_bf16_probe.py (workgroup 0 records s_memtime around the
 // sections of K step 3 of its first tile, and around that tile's epilogue; 32 values per wave in p.dbg).
+#define PP_MFMA(a, b, c, x, y, z) (DBG == 2 ? (c) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z))
+#define PP_LDS_FRAG(ptr) (DBG == 3 ? bf16x8{} : *reinterpret_cast<const bf16x8 *>(ptr))
 #define PP_STAMP(idx)                                                                                   \
     do {                                                                                                \
-        if constexpr (STAMP) {                                                                          \
+        if constexpr (STAMP == 1) {                                                                     \
             if (stamp_on) stamps[idx] = (unsigned)__builtin_amdgcn_s_memtime();                                   \
         }                                                                                               \
     } while (0)
 
-template <int EPI, bool STAMP = false>
+// DBG (timing-only builds, results wrong by construction): 1 = no LDS-DMA inside the K loop, 2 = no MFMA, 3 = no fragment reads, 4 = no epilogue.
+template <int EPI, int STAMP = 0, int DBG = 0>
 __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params p) {
-    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
-
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES + (STAMP == 2 ? 8 * 1024 : 0)];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // STAMP == 2: event log of workgroup 0, 256 words per wave in LDS: (tag << 28) | (s_memtime & 0x0fffffff);
+    // tags: 1 K-step start, 2 epilogue begin, 3 epilogue end.  Dumped to p.dbg (8 x 512 u32) at the end.
+    [[maybe_unused]] int log_n = 0;
+    auto log_event = [&](unsigned tag) __attribute__((always_inline)) {
+        if constexpr (STAMP == 2) {
+            if (blockIdx.x == 0 && log_n < 256) {
+                const unsigned t = ((unsigned)__builtin_amdgcn_s_memtime() & 0x0fffffffu) | (tag << 28);
+                if (lane == 0) *reinterpret_cast<unsigned *>(lds + LDS_BYTES + wave * 1024 + log_n * 4) = t;
+                ++log_n;
+            }
+        }
+    };
+
+    // Feature (column) order inside a wave's 64 columns.  MFMA row i = 4a + q of column group j can be fed ANY W
+    // row, so the mapping is chosen for the store pattern of the epilogue:
+    //   natural (fp32 out): n = 16j + 4a + q          -> a lane's float4 per j; 4 lanes x 16 B = 64 B per token row
+    //   paired  (bf16 out): n = 32(j>>1) + 8a + 4(j&1) + q -> a lane owns 8 consecutive features per j-pair: one 16-B
+    //                       store, 4 lanes x 16 B = 64 B per row, no transpose through LDS
+    // Both keep quadrant j>>1 = features [32(j>>1), +32), i.e. the W'0 / W'1 half-tiles.  The W slots get their
+    // own XOR key so that the 16 rows one fragment read touches stay conflict-free in either order.
+    constexpr bool PAIRED = EPI != VITHIP_BF16_EPI_F32_RESIDUAL;
 
     const int total = p.tiles_m * p.tiles_n, nwg = gridDim.x;
     const int first = xcd_remap(blockIdx.x, nwg);
     if (first >= total) return;  // workgroup-uniform
     const int nk = p.K / PBK;
+    // Identical persistent workgroups started together stay in lock-step: all 256 epilogues (32 MB of stores)
+    // hit the L2s at the same moment and every workgroup then waits for its stores to drain (vmcnt is in-order).
+    // A start-up skew of p.stagger x 512 cycles per position inside the XCD spreads them over the tile period.
+    for (int i = (blockIdx.x >> 3) * p.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(8);
 
     // ---- LDS-DMA source offsets: per half-tile two instructions (q) of 8 rows x 128 B.  Lane l lands at
     // (row L = 16*wave + 8q + l/8, chunk l%8) of the slot and fetches source chunk (l%8) ^ ((L>>1)&7).
@@ -94,20 +120,23 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     for (int q = 0; q < 2; ++q) {
         const int L = wave * 16 + q * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((L >> 1) & 7);
+        const int wkey = PAIRED ? (((L >> 1) & 1) | (((L >> 3) & 3) << 1)) : ((L >> 1) & 7);
+        const int wchunk = (lane & 7) ^ wkey;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int xrow = (L >> 6) * 128 + half * 64 + (L & 63);
             const int wrow = (L >> 5) * 64 + half * 32 + (L & 31);
             xvoff[half][q] = xrow * p.lda * 2 + chunk * 16;
-            wvoff[half][q] = wrow * p.ldw * 2 + chunk * 16;
+            wvoff[half][q] = wrow * p.ldw * 2 + wchunk * 16;
         }
     }
 
+    [[maybe_unused]] bool in_loop = false;
     // ---- load cursor (workgroup-uniform): the K step whose half-tiles are being issued
     int l_tile = first, l_kt = 0, l_tpar = 0;
     bool l_valid = true;
     __amdgpu_buffer_rsrc_t l_xr, l_wr, l_br;
-    auto set_load_tile = [&]() {
+    auto set_load_tile = [&]() __attribute__((always_inline)) {
         int tm, tn;
         tile_coords(l_tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
         const int m0 = tm * PBM, n0 = tn * PBN;
@@ -117,7 +146,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         l_br = make_rsrc(p.bias + n0, (unsigned)nrows * 4);
     };
     set_load_tile();
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
         if (++l_kt == nk) {
             l_kt = 0;
             l_tile += nwg;
@@ -127,9 +156,10 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         }
     };
     // issue half-tile KIND of the cursor's K step into the slot of K-step parity `parbit`
-    auto issue = [&](auto kind_c, int parbit) {
+    auto issue = [&](auto kind_c, int parbit) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value;
         if (!l_valid) return;
+        if (DBG == 1 && in_loop) return;
         char *dst = lds + (parbit * 4 + KIND) * SLOT + wave * 2048;
         const int koff = l_kt * (PBK * 2);
         if constexpr (KIND == 1) {
@@ -146,11 +176,22 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             __builtin_amdgcn_raw_ptr_buffer_load_lds(l_wr, (lds_void *)(dst + 1024), 16, wvoff[H][1], koff, 0, 0);
         }
     };
-    auto wait_loads = [&]() {
-        if (l_valid)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else
+    // vmcnt retires in issue order and counts stores too.  During the first K step after an epilogue the
+    // half-tile being waited for is OLDER than that epilogue's memory operations, so these may stay in flight on
+    // top of the four younger half-tiles -- otherwise every tile would begin by draining its predecessor's stores.
+    // Only when the epilogue issued exactly its nominal operations (interior tile, no predication): a count
+    // larger than what was really issued would let a needed half-tile slip.
+    constexpr int EPI_OPS = EPI == VITHIP_BF16_EPI_F32_RESIDUAL ? 55 : 16;  // stores (+ loads); 8 + 55 = vmcnt's maximum
+    int epi_slack = 0;  // waits left for which the half-tile needed is older than an unpredicated epilogue's operations
+    auto wait_loads = [&]() __attribute__((always_inline)) {
+        if (!l_valid) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (epi_slack > 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + EPI_OPS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        if (epi_slack > 0) --epi_slack;
     };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
@@ -163,10 +204,13 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     const int key = (l15 >> 1) & 7;
     const int c0 = ((l4 ^ key) & 7) * 16;
     const int xbase = (g * 64 + l15) * 128 + c0;   // + kind*SLOT + i*2048 (+ parity*64K), ^64 for ks = 1
-    const int wbase = (wc * 32 + l15) * 128 + c0;  // + kind*SLOT + j*2048
+    // W fragment of column group jj (0/1 inside the quadrant): natural row 16jj + l15, paired row 8(l15>>2) + 4jj + (l15&3)
+    const int wrow0 = PAIRED ? 8 * (l15 >> 2) + (l15 & 3) : l15;
+    const int wkey = PAIRED ? (((l15 >> 1) & 1) | ((l15 >> 2) << 1)) : key;  // same for both jj
+    const int wbase = (wc * 32 + wrow0) * 128 + ((l4 ^ wkey) & 7) * 16;       // + kind*SLOT + jj*WJ
+    constexpr int WJ = PAIRED ? 4 * 128 : 16 * 128;
 
-    // ---- compute cursor
-    int c_tile = first, c_kt = 0, c_tpar = 0, par = 0;
+    int c_tile = first, c_tpar = 0, par = 0;
     [[maybe_unused]] unsigned stamps[24];
     [[maybe_unused]] bool stamp_on = false;
     [[maybe_unused]] bool first_tile = true;
@@ -177,6 +221,193 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 xq[4][2], wq0[2][2], wq1[2][2];
+
+    // ---- epilogue of one finished tile (wave-private; no barrier): bias (+GELU | +residual), store, clear
+    auto epilogue_body = [&](int e_tile, int e_tpar) __attribute__((always_inline)) {
+        if constexpr (DBG == 4) return;  // timing probe: no epilogue at all
+        int tm, tn;
+        tile_coords(e_tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        const int mw = tm * PBM + g * 128, nw = tn * PBN + wc * 64;  // this wave's 128 x 64 block
+        f32x4 b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            b4[j] = *reinterpret_cast<const f32x4 *>(lds + BIAS_OFF + e_tpar * 1024 +
+                                                     (wc * 64 + (PAIRED ? 32 * (j >> 1) + 8 * l4 + 4 * (j & 1) : j * 16 + 4 * l4)) * 4);
+        // Full-line accesses.  In registers a lane owns row (token) l15 and two 16-B chunks of it, so a plain store
+        // instruction would write 16 rows x 64 B -- measured (tools/store_probe.py) at 14-19 B/clk per CU, against
+        // 35-57 B/clk for 8 rows x 128 B with lane = 8 * row + chunk (the coalescer works on adjacent lanes).  Every
+        // 16-row x 128-B block therefore goes through a wave-private 2-KB LDS buffer (unpadded; chunk c of row r sits
+        // at c ^ (r & 7), conflict-free both ways), two buffers per wave so that block i+1 is written while block i
+        // is read back: the first in SCRATCH, the second in this wave's eighth of the X'1 slot of the K step that
+        // just finished (nobody reads or fills that slot before the next phase 1, which is behind a barrier).
+        // Inline asm: hipcc would put `s_waitcnt vmcnt(0)` in front of ordinary LDS loads that follow LDS stores
+        // while LDS-DMA is in flight (it cannot tell these buffers from the DMA ring) and drain the prefetch queue.
+        const unsigned lds0 = (unsigned)(size_t)(lds_void *)lds;
+        const unsigned buf_a = lds0 + SCRATCH + wave * 2048;
+        const unsigned buf_b = lds0 + ((par ^ 1) * 4 + 3) * SLOT + wave * 2048;
+        const unsigned w_off = l15 * 128 + ((l4 ^ (l15 & 7)) * 16);                      // chunk l4; chunk 4 + l4 is at ^64
+        const unsigned r_off = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) * 16);  // rows 8..15 at + 1024
+        auto put = [&](int b, u32x4 c0, u32x4 c1) __attribute__((always_inline)) {
+            const unsigned base = (b & 1) ? buf_b : buf_a;
+            asm volatile("ds_write_b128 %0, %1" ::"v"(base + w_off), "v"(c0) : "memory");
+            asm volatile("ds_write_b128 %0, %1" ::"v"(base + (w_off ^ 64)), "v"(c1) : "memory");
+        };
+        auto get = [&](int b, u32x4 &ra, u32x4 &rb) __attribute__((always_inline)) {  // issue only; wait with PP_LGKM0
+            const unsigned base = ((b & 1) ? buf_b : buf_a) + r_off;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ra), "=&v"(rb) : "v"(base) : "memory");
+        };
+#define PP_LGKM0(x, y) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y)::"memory")
+        const int row8 = lane >> 3, ch8 = lane & 7;  // after the transpose: row (0..7, +8 for the second value), 16-B chunk
+        const bool interior = tm * PBM + PBM <= p.M && tn * PBN + PBN <= p.N;  // workgroup-uniform
+        epi_slack = interior ? 4 : 0;
+        if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
+            float *C = static_cast<float *>(p.C);
+            // Blocks: (m-tile i, column pair pj) = 16 rows x 32 floats; natural mapping: column groups 2pj, 2pj+1 of a
+            // lane are chunks l4 and 4 + l4.  The residual is read through the transposed (full-line) addresses.  Its
+            // reads are HBM round trips that nothing hides, and hipcc, with LDS-DMA in flight, puts vmcnt(0) in front
+            // of every use of an ordinary load -- between the stores, which serialised them on the write latency (29k
+            // cycles per tile measured).  So they are inline asm with counted waits (vmcnt retires in issue order):
+            // one block (2 loads) per batch, four batches in flight.  Counted waits need every load and store to be
+            // issued, so only tiles fully inside the matrix take that path; edge tiles predicate and wait for all.
+            constexpr int NB = 16, AHEAD = 4;
+            f32x4 res[AHEAD][2];
+            // running pointers (block order: (i, pj) = (0,0) (0,1) (1,0) ...; inside a block rows +0 and +8)
+            const float *rbase = p.R + (size_t)(mw + row8) * p.ldr + nw + ch8 * 4;
+            float *cbase = C + (size_t)(mw + row8) * p.ldc + nw + ch8 * 4;
+            size_t roff = 0, coff = 0;
+            const size_t r8 = (size_t)8 * p.ldr, c8 = (size_t)8 * p.ldc;
+            const int m_left = p.M - (mw + row8), n_left = p.N - (nw + ch8 * 4);
+            auto in_range = [&](int blk, int ab) __attribute__((always_inline)) {
+                return (blk >> 1) * 16 + ab * 8 < m_left && (blk & 1) * 32 < n_left;
+            };
+            auto load_res = [&](int blk, auto interior_c) __attribute__((always_inline)) {
+                constexpr bool INTERIOR = decltype(interior_c)::value;
+#pragma unroll
+                for (int ab = 0; ab < 2; ++ab) {
+                    f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const float *ptr = rbase + roff + ab * r8;
+                    if (INTERIOR || in_range(blk, ab)) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(ptr) : "memory");
+                    res[blk % AHEAD][ab] = r;
+                }
+                roff += (blk & 1) ? 2 * r8 - 32 : 32;  // next block: other column pair, or the next m-tile
+                asm volatile("" : "+v"(roff));
+            };
+            auto put_blk = [&](int blk) __attribute__((always_inline)) {
+                const int i = blk >> 1, pj = blk & 1;
+                put(blk, __builtin_bit_cast(u32x4, acc[i][2 * pj] + b4[2 * pj]), __builtin_bit_cast(u32x4, acc[i][2 * pj + 1] + b4[2 * pj + 1]));
+            };
+            auto run = [&](auto interior_c) __attribute__((always_inline)) {
+                constexpr bool INTERIOR = decltype(interior_c)::value;
+                u32x4 va, vb;
+#pragma unroll
+                for (int blk = 0; blk < AHEAD; ++blk) load_res(blk, interior_c);
+                put_blk(0);
+                get(0, va, vb);
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    if (blk + 1 < NB) put_blk(blk + 1);
+                    // residual of this block: younger operations = 2 loads per block still ahead + the 2 stores of each
+                    // block already stored since those loads were issued -> a constant 2 * (AHEAD - 1) + 2 * (AHEAD - 1)
+                    // in steady state; simply wait for everything on edge tiles
+                    if constexpr (INTERIOR) {
+                        const int younger_loads = 2 * ((blk + AHEAD - 1 < NB ? blk + AHEAD - 1 : NB - 1) - blk);
+                        const int younger_stores = 2 * (blk < AHEAD - 1 ? blk : AHEAD - 1);
+                        switch (younger_loads + younger_stores) {
+                            case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                            case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                            case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                            case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                            case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                            case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                            default: asm volatile("s_waitcnt vmcnt(12)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                        }
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory");
+                    }
+                    PP_LGKM0(va, vb);
+                    const f32x4 ya = __builtin_bit_cast(f32x4, va) + res[blk % AHEAD][0];
+                    const f32x4 yb = __builtin_bit_cast(f32x4, vb) + res[blk % AHEAD][1];
+                    if (INTERIOR || in_range(blk, 0)) *reinterpret_cast<f32x4 *>(cbase + coff) = ya;
+                    if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cbase + coff + c8) = yb;
+                    coff += (blk & 1) ? 2 * c8 - 32 : 32;
+                    asm volatile("" : "+v"(coff));
+                    if (blk + 1 < NB) get(blk + 1, va, vb);
+                    if (blk + AHEAD < NB) load_res(blk + AHEAD, interior_c);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the blocks apart: hoisting them together costs registers
+                }
+            };
+            if (interior)
+                run(std::true_type{});
+            else
+                run(std::false_type{});
+        } else {
+            bf16_t *C = static_cast<bf16_t *>(p.C);
+            // Blocks: m-tile i = 16 rows x 64 bf16; paired mapping: accumulators (i, 2k), (i, 2k+1) of a lane are
+            // features 32k + 8*l4 + [0,8), i.e. chunk 4k + l4.
+            auto pack = [&](int i, u32x4 &c0, u32x4 &c1) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    bf16x8 ob;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const f32x4 t4 = acc[i][2 * k + jj] + b4[2 * k + jj];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x2 v = f32x2{t4[2 * h], t4[2 * h + 1]};
+                            if constexpr (EPI == VITHIP_BF16_EPI_BF16_GELU) v = gelu_bf16_x2(v);
+                            ob[jj * 4 + 2 * h] = (__bf16)v.x;
+                            ob[jj * 4 + 2 * h + 1] = (__bf16)v.y;
+                        }
+                    }
+                    (k ? c1 : c0) = __builtin_bit_cast(u32x4, ob);
+                }
+            };
+            auto run = [&](auto interior_c) __attribute__((always_inline)) {
+                constexpr bool INTERIOR = decltype(interior_c)::value;
+                bf16_t *cbase = C + (size_t)(mw + row8) * p.ldc + nw + 8 * ch8;
+                size_t off = 0;  // advanced by 8 rows per store (one running offset, not sixteen precomputed addresses)
+                const size_t step8 = (size_t)8 * p.ldc;
+                const int m_left = p.M - (mw + row8), n = nw + 8 * ch8;  // edge tiles: rows i*16 + ab*8 < m_left are inside
+                u32x4 c0, c1, va, vb;
+                pack(0, c0, c1);
+                put(0, c0, c1);
+                get(0, va, vb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i < 7) {
+                        pack(i + 1, c0, c1);
+                        put(i + 1, c0, c1);
+                    }
+                    PP_LGKM0(va, vb);
+#pragma unroll
+                    for (int ab = 0; ab < 2; ++ab) {
+                        const u32x4 v = ab ? vb : va;
+                        bf16_t *dst = cbase + off;
+                        if (INTERIOR || (i * 16 + ab * 8 < m_left && n + 8 <= p.N)) {
+                            *reinterpret_cast<u32x4 *>(dst) = v;
+                        } else if (i * 16 + ab * 8 < m_left && n < p.N) {  // ragged N (N % 8 == 4): first half of the chunk
+                            *reinterpret_cast<uint2 *>(dst) = uint2{v.x, v.y};
+                        }
+                        off += step8;
+                        asm volatile("" : "+v"(off));
+                    }
+                    if (i < 7) get(i + 1, va, vb);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the m-tiles apart: hoisting them together costs registers
+                }
+            };
+            if (interior)
+                run(std::true_type{});
+            else
+                run(std::false_type{});
+        }
+#undef PP_LGKM0
+    };
+
+    auto epilogue = [&](int e_tile, int e_tpar) __attribute__((always_inline)) {
+        log_event(2);
+        epilogue_body(e_tile, e_tpar);
+        log_event(3);
+    };
 
     // ---- prologue: half-tiles 0..5 (K step 0 complete, kinds 0 and 1 of K step 1)
     issue(K0{}, 0);
@@ -190,31 +421,32 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     PP_BARRIER();
     if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
 
-    if constexpr (STAMP) stamps[20] = (unsigned)__builtin_amdgcn_s_memtime();
-    for (;;) {
-        if constexpr (STAMP) stamp_on = blockIdx.x == 0 && first_tile && c_kt == 3;
-        PP_STAMP(0);
-        const char *cur = lds + (par << 16);
-        const char *xb0 = cur + xbase, *xb1 = cur + (xbase ^ 64);
-        const char *wb0 = cur + wbase, *wb1 = cur + (wbase ^ 64);
+    if constexpr (STAMP == 1) stamps[20] = (unsigned)__builtin_amdgcn_s_memtime();
+    in_loop = true;
 
-        // ================= phase 0: quadrant (m0, n0) =================
+    // ---- the four phases of a K step.  `cur` (LDS byte offset of the K step's parity) is refreshed per K step.
+    const char *xb0, *xb1, *wb0, *wb1;
+    auto kstep_bases = [&]() __attribute__((always_inline)) {
+        const char *cur = lds + (par << 16);
+        xb0 = cur + xbase;
+        xb1 = cur + (xbase ^ 64);
+        wb0 = cur + wbase;
+        wb1 = cur + (wbase ^ 64);
+    };
+    auto reads0 = [&]() __attribute__((always_inline)) {  // W'0 (4 fragments) + X'0 (8 fragments)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            wq0[j][0] = *reinterpret_cast<const bf16x8 *>(wb0 + 1 * SLOT + j * 2048);
-            wq0[j][1] = *reinterpret_cast<const bf16x8 *>(wb1 + 1 * SLOT + j * 2048);
+            wq0[j][0] = PP_LDS_FRAG(wb0 + 1 * SLOT + j * WJ);
+            wq0[j][1] = PP_LDS_FRAG(wb1 + 1 * SLOT + j * WJ);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            xq[i][0] = *reinterpret_cast<const bf16x8 *>(xb0 + 0 * SLOT + i * 2048);
-            xq[i][1] = *reinterpret_cast<const bf16x8 *>(xb1 + 0 * SLOT + i * 2048);
+            xq[i][0] = PP_LDS_FRAG(xb0 + 0 * SLOT + i * 2048);
+            xq[i][1] = PP_LDS_FRAG(xb1 + 0 * SLOT + i * 2048);
         }
-        issue(K2{}, par ^ 1);
-        wait_loads();
-        PP_STAMP(1);
-        PP_BARRIER();
-        PP_STAMP(2);
+    };
+    auto mfma0 = [&]() __attribute__((always_inline)) {  // quadrant (m0, n0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -223,17 +455,26 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq0[j][ks], xq[i][ks], acc[i][j], 0, 0, 0);
+                    acc[i][j] = PP_MFMA(wq0[j][ks], xq[i][ks], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+    };
+    auto phase0 = [&]() __attribute__((always_inline)) {
+        reads0();
+        issue(K2{}, par ^ 1);
+        wait_loads();
+        PP_STAMP(1);
+        PP_BARRIER();
+        PP_STAMP(2);
+        mfma0();
         PP_STAMP(3);
         PP_BARRIER();
         PP_STAMP(4);
-
-        // ================= phase 1: quadrant (m0, n1) =================
+    };
+    auto phase1 = [&]() __attribute__((always_inline)) {  // quadrant (m0, n1)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            wq1[j][0] = *reinterpret_cast<const bf16x8 *>(wb0 + 2 * SLOT + j * 2048);
-            wq1[j][1] = *reinterpret_cast<const bf16x8 *>(wb1 + 2 * SLOT + j * 2048);
+            wq1[j][0] = PP_LDS_FRAG(wb0 + 2 * SLOT + j * WJ);
+            wq1[j][1] = PP_LDS_FRAG(wb1 + 2 * SLOT + j * WJ);
         }
         issue(K3{}, par ^ 1);
         wait_loads();
@@ -248,17 +489,17 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq1[j][ks], xq[i][ks], acc[i][2 + j], 0, 0, 0);
+                    acc[i][2 + j] = PP_MFMA(wq1[j][ks], xq[i][ks], acc[i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_STAMP(8);
         PP_BARRIER();
         PP_STAMP(9);
-
-        // ================= phase 2: quadrant (m1, n1) =================
+    };
+    auto phase2 = [&]() __attribute__((always_inline)) {  // quadrant (m1, n1)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            xq[i][0] = *reinterpret_cast<const bf16x8 *>(xb0 + 3 * SLOT + i * 2048);
-            xq[i][1] = *reinterpret_cast<const bf16x8 *>(xb1 + 3 * SLOT + i * 2048);
+            xq[i][0] = PP_LDS_FRAG(xb0 + 3 * SLOT + i * 2048);
+            xq[i][1] = PP_LDS_FRAG(xb1 + 3 * SLOT + i * 2048);
         }
         advance();
         issue(K0{}, par);
@@ -274,13 +515,13 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq1[j][ks], xq[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+                    acc[4 + i][2 + j] = PP_MFMA(wq1[j][ks], xq[i][ks], acc[4 + i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_STAMP(13);
         PP_BARRIER();
         PP_STAMP(14);
-
-        // ================= phase 3: quadrant (m1, n0) =================
+    };
+    auto phase3 = [&]() __attribute__((always_inline)) {  // quadrant (m1, n0); no fragment reads
         issue(K1{}, par);
         wait_loads();
         PP_STAMP(16);
@@ -293,177 +534,91 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq0[j][ks], xq[i][ks], acc[4 + i][j], 0, 0, 0);
+                    acc[4 + i][j] = PP_MFMA(wq0[j][ks], xq[i][ks], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_STAMP(18);
         PP_BARRIER();
         PP_STAMP(19);
+    };
 
+    // ---- tile loop.  Epilogues: group 1 runs its own right after its last phase (before the load section of its
+    // next phase 0); group 0 DEFERS its by one barrier interval, to just before the MFMAs of its next phase 0 -- the
+    // same interval, so the two epilogues overlap each other instead of each stalling the other group at a barrier
+    // (measured before: two back-to-back epilogues of 5-10k cycles per 37k-cycle tile).  K step 0 of every tile is
+    // peeled so that this happens in straight-line code and the accumulators are (re)defined unconditionally.
+    bool have_prev = false;
+    int prev_tile = 0, prev_tpar = 0;
+    for (;;) {
+        // ================= K step 0 =================
+        log_event(1);
+        kstep_bases();
+        if (g == 0 && have_prev) {
+            issue(K2{}, par ^ 1);
+            wait_loads();
+            PP_BARRIER();
+            epilogue(prev_tile, prev_tpar);
+            __builtin_amdgcn_sched_barrier(0);
+            reads0();  // after the epilogue: its temporaries and these fragments do not fit together
+        } else {
+            reads0();
+            issue(K2{}, par ^ 1);
+            wait_loads();
+            PP_BARRIER();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mfma0();
+        PP_BARRIER();
+        phase1();
+        phase2();
+        phase3();
         par ^= 1;
-        if (++c_kt < nk) continue;
-
-        // ================= epilogue of tile c_tile (wave-private; no barrier) =================
-        if constexpr (STAMP) {
+        // ================= K steps 1 .. nk-1 =================
+        for (int kt = 1; kt < nk; ++kt) {
+            if constexpr (STAMP == 1) stamp_on = blockIdx.x == 0 && first_tile && kt == 3;
+            PP_STAMP(0);
+            log_event(1);
+            kstep_bases();
+            phase0();
+            phase1();
+            phase2();
+            phase3();
+            par ^= 1;
+        }
+        // ================= tile finished =================
+        if constexpr (STAMP == 1) {
             if (first_tile) stamps[21] = (unsigned)__builtin_amdgcn_s_memtime();
         }
-        {
-            int tm, tn;
-            tile_coords(c_tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-            const int mw = tm * PBM + g * 128, nw = tn * PBN + wc * 64;  // this wave's 128 x 64 block
-            f32x4 b4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b4[j] = *reinterpret_cast<const f32x4 *>(lds + BIAS_OFF + c_tpar * 1024 + (wc * 64 + j * 16 + 4 * l4) * 4);
-            if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
-                float *C = static_cast<float *>(p.C);
-                // The residual reads are HBM round trips that nothing hides (the accumulators are final only now), and
-                // hipcc, with LDS-DMA in flight, puts vmcnt(0) in front of every use of an ordinary load -- between
-                // the stores that serialised them on the write latency (29k cycles per tile measured).  So the loads
-                // are inline asm with counted waits (vmcnt retires in issue order): four batches of 8 loads (2 m-tiles),
-                // two batches in flight.
-                // Counted waits need every load and store to be issued, so only tiles that lie fully inside
-                // the matrix take this path; edge tiles predicate their accesses and wait for everything.
-                f32x4 res[2][2][4];
-                const bool interior = tm * PBM + PBM <= p.M && tn * PBN + PBN <= p.N;  // workgroup-uniform
-                auto load_batch = [&](int b, auto interior_c) {  // m-tiles 2b, 2b+1 into res[b & 1]
-                    constexpr bool INTERIOR = decltype(interior_c)::value;
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const int m = mw + (2 * b + ii) * 16 + l15;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int n = nw + j * 16 + 4 * l4;
-                            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
-                            const float *ptr = p.R + (size_t)m * p.ldr + n;
-                            if (INTERIOR || (m < p.M && n < p.N))
-                                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(ptr) : "memory");
-                            res[b & 1][ii][j] = r;
-                        }
-                    }
-                };
-                auto store_batch = [&](int b, auto interior_c) {
-                    constexpr bool INTERIOR = decltype(interior_c)::value;
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const int i = 2 * b + ii;
-                        const int m = mw + i * 16 + l15;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int n = nw + j * 16 + 4 * l4;
-                            if (INTERIOR || (m < p.M && n < p.N))
-                                *reinterpret_cast<f32x4 *>(C + (size_t)m * p.ldc + n) = acc[i][j] + b4[j] + res[b & 1][ii][j];
-                        }
-                    }
-                };
-#define PP_WAIT_RES(N, b)                                                                                             \
-    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                            \
-                 : "+v"(res[b][0][0]), "+v"(res[b][0][1]), "+v"(res[b][0][2]), "+v"(res[b][0][3]), "+v"(res[b][1][0]), \
-                   "+v"(res[b][1][1]), "+v"(res[b][1][2]), "+v"(res[b][1][3])::"memory")
-                if (interior) {
-                    using T = std::true_type;
-                    load_batch(0, T{});
-                    load_batch(1, T{});
-                    PP_WAIT_RES(8, 0);   // younger: the 8 loads of batch 1
-                    store_batch(0, T{});
-                    load_batch(2, T{});
-                    PP_WAIT_RES(16, 1);  // younger: 8 stores + 8 loads
-                    store_batch(1, T{});
-                    load_batch(3, T{});
-                    PP_WAIT_RES(16, 0);
-                    store_batch(2, T{});
-                    PP_WAIT_RES(8, 1);   // younger: the 8 stores of batch 2
-                    store_batch(3, T{});
-                } else {
-                    using F = std::false_type;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        load_batch(b, F{});
-                        if (b & 1)
-                            PP_WAIT_RES(0, 1);
-                        else
-                            PP_WAIT_RES(0, 0);
-                        store_batch(b, F{});
-                    }
-                }
-#undef PP_WAIT_RES
-            } else {
-                bf16_t *C = static_cast<bf16_t *>(p.C);
-                // wave-private transpose scratch, addressed with inline asm: hipcc puts `s_waitcnt vmcnt(0)` in
-                // front of an ordinary LDS load that follows an LDS store while LDS-DMA is in flight (it cannot
-                // tell the scratch from the DMA ring), which would drain the prefetch queue once per tile.
-                const unsigned scr = (unsigned)(size_t)(lds_void *)(lds + RING + wave * SCR_WAVE);
-                const unsigned scr_w = scr + l15 * SCR_PITCH + l4 * 8;                 // + j*32
-                const unsigned scr_r = scr + (lane >> 3) * SCR_PITCH + (lane & 7) * 16;  // + h*8*SCR_PITCH
-                // m-tile i: 4 x ds_write_b64 (lane's 4 features per column group) -> 2 x ds_read_b128 (8 features of one
-                // token) -> 2 x 16-B stores; the bias/GELU/convert arithmetic of m-tile i+1 runs while the reads of
-                // m-tile i are in flight (LDS executes a wave's operations in order, so write -> read needs no wait).
-                auto pack = [&](int i, uint2(&ob)[4]) {
-                    float y[16];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) y[j * 4 + q] = acc[i][j][q] + b4[j][q];
-                    if constexpr (EPI == VITHIP_BF16_EPI_BF16_GELU) {
-                        gelu_erf_x8(*reinterpret_cast<float(*)[8]>(&y[0]));
-                        gelu_erf_x8(*reinterpret_cast<float(*)[8]>(&y[8]));
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bf16x4 o;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = (__bf16)y[j * 4 + q];
-                        ob[j] = __builtin_bit_cast(uint2, o);
-                    }
-                };
-                u32x4 v0, v1;
-                auto write_read = [&](const uint2(&ob)[4]) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(scr_w), "v"(ob[j]), "n"(j * 32) : "memory");
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"
-                                 : "=&v"(v0), "=&v"(v1)
-                                 : "v"(scr_r), "n"(8 * SCR_PITCH)
-                                 : "memory");
-                };
-                uint2 ob[4];
-                pack(0, ob);
-                write_read(ob);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (i < 7) pack(i + 1, ob);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const u32x4 v = h ? v1 : v0;
-                        const int m = mw + i * 16 + h * 8 + (lane >> 3), n = nw + (lane & 7) * 8;
-                        if (m < p.M && n + 8 <= p.N) {
-                            *reinterpret_cast<u32x4 *>(C + (size_t)m * p.ldc + n) = v;
-                        } else if (m < p.M && n < p.N) {  // ragged N (N % 8 == 4): first half of the chunk
-                            *reinterpret_cast<uint2 *>(C + (size_t)m * p.ldc + n) = uint2{v.x, v.y};
-                        }
-                    }
-                    if (i < 7) write_read(ob);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if constexpr (STAMP) {
+        if (g == 1) epilogue(c_tile, c_tpar);
+        if constexpr (STAMP == 1) {
             if (first_tile) stamps[22] = (unsigned)__builtin_amdgcn_s_memtime();
             first_tile = false;
         }
-        c_kt = 0;
+        prev_tile = c_tile;
+        prev_tpar = c_tpar;
+        have_prev = true;
         c_tpar ^= 1;
         c_tile += nwg;
         if (c_tile >= total) break;
     }
-    if (g == 0) PP_BARRIER();  // pairs with group 1's last barrier
-    if constexpr (STAMP) {
+    if (g == 0) {
+        epilogue(prev_tile, prev_tpar);  // group 0's last tile
+        PP_BARRIER();                    // pairs with group 1's last barrier
+    }
+    if constexpr (STAMP == 1) {
         stamps[23] = (unsigned)__builtin_amdgcn_s_memtime();
         if (blockIdx.x == 0 && lane == 0)
             for (int k = 0; k < 24; ++k) p.dbg[wave * 32 + k] = stamps[k];
+    }
+    if constexpr (STAMP == 2) {
+        log_event(4);
+        if (blockIdx.x == 0) {
+            unsigned *out = reinterpret_cast<unsigned *>(p.dbg);
+            for (int k = lane; k < 512; k += 64)
+                out[wave * 512 + k] = k < log_n ? *reinterpret_cast<unsigned *>(lds + LDS_BYTES + wave * 1024 + k * 4) : 0u;
+        }
     }
 }
 
@@ -476,9 +631,15 @@ int launch_gemm_bf16_pp(hipStream_t s, const Bf16Params &p, int epilogue, int cu
         case VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL>, grid, block, 0, s, p); break;
-        case 100 + VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, true>), grid, block, 0, s, p); break;
-        case 100 + VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU, true>), grid, block, 0, s, p); break;
-        case 100 + VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL, true>), grid, block, 0, s, p); break;
+        case 201: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 1>), grid, block, 0, s, p); break;
+        case 202: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 2>), grid, block, 0, s, p); break;
+        case 203: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 3>), grid, block, 0, s, p); break;
+        case 204: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 4>), grid, block, 0, s, p); break;
+        case 300 + VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 2>), grid, block, 0, s, p); break;
+        case 300 + VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL, 2>), grid, block, 0, s, p); break;
+        case 100 + VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 1>), grid, block, 0, s, p); break;
+        case 100 + VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU, 1>), grid, block, 0, s, p); break;
+        case 100 + VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL, 1>), grid, block, 0, s, p); break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());

@@ -116,6 +116,33 @@ __global__ __launch_bounds__(512) void mfma_vs_gelu_kernel(float *out, int iters
         if (s == 12345.678f) out[1] = s;
     }
 }
+// Store-path probe: every wave issues `iters` x 16-byte-per-lane stores.  mode 0: 1 KB contiguous per instruction;
+// mode 1: 16 rows x 64 B (row stride `stride` bytes), the GEMM epilogue's fragment pattern; mode 2: 8 rows x 128 B.
+// Reports s_memtime cycles from the first store issue to the last ISSUE (not completion) and to completion.
+__global__ __launch_bounds__(512) void store_probe_kernel(float4 *out, int iters, int mode, size_t stride, unsigned long long *cyc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwave = blockDim.x >> 6;
+    char *base = reinterpret_cast<char *>(out) + ((size_t)blockIdx.x * nwave + wave) * (size_t)iters * 16 * stride;
+    size_t off;
+    if (mode == 0) off = (size_t)lane * 16;
+    else if (mode == 1) off = (size_t)(lane & 15) * stride + (lane >> 4) * 16;
+    else off = (size_t)(lane >> 3) * stride + (lane & 7) * 16;
+    const float4 v = make_float4(1.f, 2.f, 3.f, (float)lane);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const size_t adv = mode == 0 ? (size_t)it * 1024 : (mode == 1 ? (size_t)it * 16 * stride : (size_t)it * 8 * stride);
+        *reinterpret_cast<float4 *>(base + off + adv) = v;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        cyc[((size_t)blockIdx.x * nwave + wave) * 2] = t1 - t0;
+        cyc[((size_t)blockIdx.x * nwave + wave) * 2 + 1] = t2 - t0;
+    }
+}
+
 }  // namespace
 
 extern "C" int vithip_probe_mfma_vs_gelu(vithip_stream_t stream, float *out, int blocks, int iters, int gelu_iters, int mode) {
@@ -135,5 +162,11 @@ extern "C" int vithip_probe_mfma_vs_valu(vithip_stream_t stream, float *out, int
 extern "C" int vithip_probe_mfma_f32(vithip_stream_t stream, float *out, int blocks, int threads, int iters) {
     hipLaunchKernelGGL(mfma_f32_loop_kernel, dim3(blocks), dim3(threads), 0, static_cast<hipStream_t>(stream), out,
                        iters, 0.37f);
+    return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int vithip_probe_store(vithip_stream_t stream, void *out, int blocks, int threads, int iters, int mode, size_t stride, void *cycles) {
+    hipLaunchKernelGGL(store_probe_kernel, dim3(blocks), dim3(threads), 0, static_cast<hipStream_t>(stream),
+                       static_cast<float4 *>(out), iters, mode, stride, static_cast<unsigned long long *>(cycles));
     return static_cast<int>(hipGetLastError());
 }
