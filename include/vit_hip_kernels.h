@@ -106,7 +106,8 @@ int vithip_gemm_set_group(int group_m);
 
 /* ---- bf16 variant (BASELINE.json configs[2]) ---------------------------------
  * bf16 values are raw uint16 (upper half of the fp32 bit pattern, round-to-nearest-even). */
-enum { VITHIP_BF16_EPI_BF16 = 0, VITHIP_BF16_EPI_BF16_GELU = 1, VITHIP_BF16_EPI_F32_RESIDUAL = 2 };
+enum { VITHIP_BF16_EPI_BF16 = 0, VITHIP_BF16_EPI_BF16_GELU = 1, VITHIP_BF16_EPI_F32_RESIDUAL = 2,
+       VITHIP_BF16_EPI_F32_EMBED = 3 /* internal to vithip_patch_embed_bf16 */ };
 typedef struct {
     const unsigned short *A; int lda;   /* bf16 [M][lda], K contiguous */
     const unsigned short *W; int ldw;   /* bf16 [N][ldw] */
@@ -135,6 +136,15 @@ int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, u
                             int n_images, int tokens, int heads);
 /* 1 (default): tokens <= 224 run both attention products on bf16 MFMA (P rounded to bf16); 0: fp32 MFMA. */
 int vithip_attention_bf16_set_mfma(int on);
+/* Patch embedding on the bf16 matrix pipe (same result layout as vithip_patch_embed_f32: x[n][tokens][D] fp32 with
+ * class token and pos_emb applied; ViT_seq.c:25-101): the images are cut into bf16 patch rows
+ * (patches16: workspace of n * (img/patch)^2 * chans*patch^2 bf16), multiplied with the bf16 conv weight
+ * conv_w16 [D][chans*patch^2] with fp32 accumulation, bias / pos_emb / class token added in fp32.
+ * Needs chans*patch^2 % 64 == 0, chans*patch^2 >= 128, D % 4 == 0, patch % 8 == 0. */
+int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const unsigned short *conv_w16,
+                            const float *conv_b, const float *cls, const float *pos, float *x,
+                            unsigned short *patches16, int n_images, int img_size, int patch_size, int in_chans,
+                            int embed_dim);
 /* dst[i] = bf16(src[i]), round to nearest even; count % 4 == 0. */
 int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short *dst, size_t count);
 

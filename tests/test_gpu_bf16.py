@@ -84,6 +84,23 @@ def test_gemm_bf16_persistent_many_tiles(variant, epi, M, N, K):
     assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), float(err.max())
 
 
+@pytest.mark.parametrize("cfg,n", [(synth.VIT_B16, 3), (synth.VIT_SMALL, 5)])
+def test_patch_embed_bf16(oracle, cfg, n):
+    """Patch embedding on the bf16 pipe vs the oracle's conv/flatten/class-token/pos_emb on the SAME bf16-rounded
+    pixels and conv weights: only the fp32 accumulation order differs."""
+    from conftest import oracle_config
+    W = [synth.make_weight(cfg, i, 5) for i in range(4)]
+    imgs = synth.make_images(cfg, n, 6)
+    got = B.patch_embed_bf16(cfg, imgs, W[1], W[2], W[0], W[3])
+    Wr = list(W)
+    Wr[1] = B.from_bf16_bits(B.to_bf16_bits(W[1])).reshape(W[1].shape)
+    imgs_r = B.from_bf16_bits(B.to_bf16_bits(imgs)).reshape(imgs.shape)
+    ocfg = oracle_config(cfg)
+    for i in range(n):
+        ref = oracle.embed(ocfg, imgs_r[i], Wr)
+        assert float(np.abs(got[i] - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
 def test_layernorm_bf16_out(oracle):
     x = u(10, (197, 768), 3.0) + 0.5
     g, b = synth.uniform(999, 11, 768, 0.5, 1.5), u(12, (768,), 0.5)

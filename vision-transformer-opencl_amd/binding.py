@@ -320,6 +320,21 @@ def patch_embed(cfg: ModelConfig, images, conv_w, conv_b, cls, pos) -> np.ndarra
     return dx.numpy().reshape(n, cfg.tokens, cfg.embed_dim)
 
 
+def patch_embed_bf16(cfg: ModelConfig, images, conv_w, conv_b, cls, pos) -> np.ndarray:
+    """vithip_patch_embed_bf16: conv weight given in fp32 and rounded to bf16 here (as the engine does on upload)."""
+    images = _as_f32(images)
+    n = images.shape[0]
+    L = lib()
+    L.vithip_patch_embed_bf16.argtypes = [C.c_void_p] * 8 + [C.c_int] * 5
+    d = [DeviceArray.from_numpy(_as_f32(a)) for a in (images, conv_b, cls, pos)]
+    dw = DeviceArray.from_numpy(to_bf16_bits(_as_f32(conv_w).reshape(cfg.embed_dim, -1)))
+    dx = DeviceArray((n * cfg.tokens, cfg.embed_dim))
+    dp = DeviceArray((n * cfg.patches, cfg.patch_dim), np.uint16)
+    hip_check(L.vithip_patch_embed_bf16(None, d[0].ptr, dw.ptr, d[1].ptr, d[2].ptr, d[3].ptr, dx.ptr, dp.ptr, n,
+                                        cfg.img_size, cfg.patch_size, cfg.in_chans, cfg.embed_dim), "vithip_patch_embed_bf16")
+    return dx.numpy().reshape(n, cfg.tokens, cfg.embed_dim)
+
+
 def softmax_top1(logits):
     logits = _as_f32(logits)
     rows, classes = logits.shape

@@ -261,6 +261,40 @@ __global__ void f32_to_bf16_kernel(const float *__restrict__ src, bf16_t *__rest
     }
 }
 
+// images fp32 NCHW -> patch rows bf16 [n * G * G][C * P * P], column order (c, kh, kw) = the conv weight's.
+// One thread converts 8 consecutive pixels of an image row (32 B in, 16 B out).
+__global__ void patchify_bf16_kernel(const float *__restrict__ images, bf16_t *__restrict__ patches, int n_images, int S, int P,
+                                     int C) {
+    const int G = S / P, x8n = S / 8;
+    const size_t total = (size_t)n_images * C * S * x8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x8 = (int)(i % x8n);
+        size_t r = i / x8n;
+        const int y = (int)(r % S);
+        r /= S;
+        const int c = (int)(r % C);
+        const int im = (int)(r / C);
+        const float *src = images + (((size_t)im * C + c) * S + y) * S + x8 * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[q] = (__bf16)a[q];
+            o[4 + q] = (__bf16)b[q];
+        }
+        const int px = (x8 * 8) / P, kw = (x8 * 8) % P, py = y / P, kh = y % P;
+        bf16_t *dst = patches + ((size_t)im * G * G + (size_t)py * G + px) * ((size_t)C * P * P) + ((size_t)c * P + kh) * P + kw;
+        *reinterpret_cast<bf16x8 *>(dst) = o;
+    }
+}
+
+__global__ void cls_rows_bf16path_kernel(const float *cls, const float *pos, float *x, int n_images, int tokens, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images * dim) return;
+    const int im = i / dim, d = i - im * dim;
+    x[(size_t)im * tokens * dim + d] = cls[d] + pos[d];  // class_token + pos_emb row 0 (ViT_seq.c:72-101)
+}
+
 bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
 int g_cus = 0;      // CU count, queried once
 int g_variant = 0;  // 0 auto (ping-pong kernel when its preconditions hold), 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong
@@ -305,6 +339,43 @@ int vithip_gemm_bf16_set_debug_buffer(void *buf) {
     return 0;
 }
 
+int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const unsigned short *conv_w16, const float *conv_b,
+                            const float *cls, const float *pos, float *x, unsigned short *patches16, int n_images,
+                            int img_size, int patch_size, int in_chans, int embed_dim) {
+    if (!images || !conv_w16 || !conv_b || !cls || !pos || !x || !patches16 || n_images <= 0)
+        return static_cast<int>(hipErrorInvalidValue);
+    if (patch_size <= 0 || patch_size % 8 || img_size % patch_size || in_chans <= 0 || embed_dim % 4)
+        return static_cast<int>(hipErrorInvalidValue);
+    const int G = img_size / patch_size, P = G * G, K = in_chans * patch_size * patch_size;
+    if (K % TBK || K < 2 * TBK) return static_cast<int>(hipErrorInvalidValue);
+    if (!aligned16(images) || !aligned16(conv_w16) || !aligned16(conv_b) || !aligned16(pos) || !aligned16(x) || !aligned16(patches16))
+        return static_cast<int>(hipErrorInvalidValue);
+    if ((size_t)n_images * P > 0x7fffffffu / 2) return static_cast<int>(hipErrorInvalidValue);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t work = (size_t)n_images * in_chans * img_size * (img_size / 8);
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(patchify_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, images, patches16, n_images, img_size,
+                       patch_size, in_chans);
+    const int total = n_images * embed_dim;
+    hipLaunchKernelGGL(cls_rows_bf16path_kernel, dim3((total + 255) / 256), dim3(256), 0, s, cls, pos, x, n_images, P + 1, embed_dim);
+    Bf16Params p{};
+    p.A = patches16; p.W = conv_w16; p.bias = conv_b; p.R = pos; p.C = x;
+    p.lda = K; p.ldw = K; p.ldr = embed_dim; p.ldc = embed_dim;
+    p.M = n_images * P; p.N = embed_dim; p.K = K;
+    p.tiles_m = (p.M + TBM - 1) / TBM;
+    p.tiles_n = (p.N + TBN - 1) / TBN;
+    p.group_m = 8;
+    p.patches = P;
+    p.stagger = g_stagger;
+    if (g_cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return static_cast<int>(hipErrorInvalidDevice);
+    }
+    return vitgemm::launch_gemm_bf16_pp(s, p, VITHIP_BF16_EPI_F32_EMBED, g_cus);
+}
+
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->K % TBK || a->N % 4) return static_cast<int>(hipErrorInvalidValue);
@@ -333,7 +404,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     // ping-pong kernel: needs two K steps per tile (its bias slot is recycled every second tile) and
     // operands addressable through 32-bit buffer offsets inside one tile (always true: 256 rows)
     if (a->epilogue >= 201 && a->epilogue <= 204) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);  // timing probes
-    const bool pp_ok = p.K >= 2 * TBK && a->epilogue <= VITHIP_BF16_EPI_F32_RESIDUAL &&
+    const bool pp_ok = p.K >= 2 * TBK && a->epilogue >= 0 && a->epilogue <= VITHIP_BF16_EPI_F32_RESIDUAL &&
                        (size_t)p.lda * 2 * 256 < (1u << 31) && (size_t)p.ldw * 2 * 256 < (1u << 31);
     if (g_variant >= 2 && !pp_ok) return static_cast<int>(hipErrorInvalidValue);
     if (g_variant == 3) {

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     //                       store, 4 lanes x 16 B = 64 B per row, no transpose through LDS
     // Both keep quadrant j>>1 = features [32(j>>1), +32), i.e. the W'0 / W'1 half-tiles.  The W slots get their
     // own XOR key so that the 16 rows one fragment read touches stay conflict-free in either order.
-    constexpr bool PAIRED = EPI != VITHIP_BF16_EPI_F32_RESIDUAL;
+    constexpr bool F32OUT = EPI == VITHIP_BF16_EPI_F32_RESIDUAL || EPI == VITHIP_BF16_EPI_F32_EMBED;
+    constexpr bool PAIRED = !F32OUT;
 
     const int total = p.tiles_m * p.tiles_n, nwg = gridDim.x;
     const int first = xcd_remap(blockIdx.x, nwg);
@@ -136,23 +137,30 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     int l_tile = first, l_kt = 0, l_tpar = 0;
     bool l_valid = true;
     __amdgpu_buffer_rsrc_t l_xr, l_wr, l_br;
-    auto set_load_tile = [&]() __attribute__((always_inline)) {
+    __amdgpu_buffer_rsrc_t n_xr, n_wr, n_br;  // descriptors of the cursor's NEXT tile, prepared ahead of the switch
+    auto tile_rsrc = [&](int tile, __amdgpu_buffer_rsrc_t &xr, __amdgpu_buffer_rsrc_t &wr, __amdgpu_buffer_rsrc_t &br) __attribute__((always_inline)) {
         int tm, tn;
-        tile_coords(l_tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        tile_coords(tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
         const int m0 = tm * PBM, n0 = tn * PBN;
         const int mrows = p.M - m0 < PBM ? p.M - m0 : PBM, nrows = p.N - n0 < PBN ? p.N - n0 : PBN;
-        l_xr = make_rsrc(p.A + (size_t)m0 * p.lda, (unsigned)mrows * p.lda * 2);  // rows past M read as zero
-        l_wr = make_rsrc(p.W + (size_t)n0 * p.ldw, (unsigned)nrows * p.ldw * 2);
-        l_br = make_rsrc(p.bias + n0, (unsigned)nrows * 4);
+        xr = make_rsrc(p.A + (size_t)m0 * p.lda, (unsigned)mrows * p.lda * 2);  // rows past M read as zero
+        wr = make_rsrc(p.W + (size_t)n0 * p.ldw, (unsigned)nrows * p.ldw * 2);
+        br = make_rsrc(p.bias + n0, (unsigned)nrows * 4);
     };
-    set_load_tile();
+    tile_rsrc(l_tile, l_xr, l_wr, l_br);
+    n_xr = l_xr, n_wr = l_wr, n_br = l_br;
+    // The tile switch costs two integer divisions (tile_coords); in a load section that was +700 cycles on the critical
+    // path once per tile.  prepare_next() runs between the MFMAs of phase 1 of the last K step before the switch.
+    auto prepare_next = [&]() __attribute__((always_inline)) {
+        if (l_kt == nk - 1 && l_tile + nwg < total) tile_rsrc(l_tile + nwg, n_xr, n_wr, n_br);
+    };
     auto advance = [&]() __attribute__((always_inline)) {
         if (++l_kt == nk) {
             l_kt = 0;
             l_tile += nwg;
             l_tpar ^= 1;
             l_valid = l_tile < total;
-            if (l_valid) set_load_tile();
+            l_xr = n_xr, l_wr = n_wr, l_br = n_br;
         }
     };
     // issue half-tile KIND of the cursor's K step into the slot of K-step parity `parbit`
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     // top of the four younger half-tiles -- otherwise every tile would begin by draining its predecessor's stores.
     // Only when the epilogue issued exactly its nominal operations (interior tile, no predication): a count
     // larger than what was really issued would let a needed half-tile slip.
-    constexpr int EPI_OPS = EPI == VITHIP_BF16_EPI_F32_RESIDUAL ? 55 : 16;  // stores (+ loads); 8 + 55 = vmcnt's maximum
+    constexpr int EPI_OPS = F32OUT ? 55 : 16;  // stores (+ loads); 8 + 55 = vmcnt's maximum
     int epi_slack = 0;  // waits left for which the half-tile needed is older than an unpredicated epilogue's operations
     auto wait_loads = [&]() __attribute__((always_inline)) {
         if (!l_valid) {
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         const int row8 = lane >> 3, ch8 = lane & 7;  // after the transpose: row (0..7, +8 for the second value), 16-B chunk
         const bool interior = tm * PBM + PBM <= p.M && tn * PBN + PBN <= p.N;  // workgroup-uniform
         epi_slack = interior ? 4 : 0;
-        if constexpr (EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
+        if constexpr (F32OUT) {
             float *C = static_cast<float *>(p.C);
             // Blocks: (m-tile i, column pair pj) = 16 rows x 32 floats; natural mapping: column groups 2pj, 2pj+1 of a
             // lane are chunks l4 and 4 + l4.  The residual is read through the transposed (full-line) addresses.  Its
@@ -280,13 +288,32 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             auto in_range = [&](int blk, int ab) __attribute__((always_inline)) {
                 return (blk >> 1) * 16 + ab * 8 < m_left && (blk & 1) * 32 < n_left;
             };
+            // F32_EMBED (patch embedding): GEMM row m = image * P + patch goes to token row m + image + 1 of x (row 0 of
+            // every image is the class token), and the "residual" is pos_emb row patch + 1 (ViT_seq.c:52-101).
+            [[maybe_unused]] auto embed_rows = [&](int blk, int ab, size_t &pos_row, size_t &out_row) __attribute__((always_inline)) {
+                const int m = mw + (blk >> 1) * 16 + ab * 8 + row8;
+                const int im = m / p.patches, pp = m - im * p.patches;
+                pos_row = (size_t)pp + 1;
+                out_row = (size_t)m + im + 1;
+            };
             auto load_res = [&](int blk, auto interior_c) __attribute__((always_inline)) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
 #pragma unroll
                 for (int ab = 0; ab < 2; ++ab) {
                     f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
                     const float *ptr = rbase + roff + ab * r8;
-                    if (INTERIOR || in_range(blk, ab)) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(ptr) : "memory");
+                    if constexpr (EPI == VITHIP_BF16_EPI_F32_EMBED) {
+                        size_t pos_row, out_row;
+                        embed_rows(blk, ab, pos_row, out_row);
+                        ptr = p.R + pos_row * p.ldr + nw + (blk & 1) * 32 + ch8 * 4;
+                    }
+                    if constexpr (INTERIOR) {
+                        // asynchronous: the value is only valid after the counted wait below.  Safe only in straight-line
+                        // code (no predication, so no compiler-made copies of `r` before the data has arrived).
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(ptr) : "memory");
+                    } else if (in_range(blk, ab)) {
+                        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "+v"(r) : "v"(ptr) : "memory");
+                    }
                     res[blk % AHEAD][ab] = r;
                 }
                 roff += (blk & 1) ? 2 * r8 - 32 : 32;  // next block: other column pair, or the next m-tile
@@ -327,8 +354,16 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     PP_LGKM0(va, vb);
                     const f32x4 ya = __builtin_bit_cast(f32x4, va) + res[blk % AHEAD][0];
                     const f32x4 yb = __builtin_bit_cast(f32x4, vb) + res[blk % AHEAD][1];
-                    if (INTERIOR || in_range(blk, 0)) *reinterpret_cast<f32x4 *>(cbase + coff) = ya;
-                    if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cbase + coff + c8) = yb;
+                    float *ca = cbase + coff, *cb = cbase + coff + c8;
+                    if constexpr (EPI == VITHIP_BF16_EPI_F32_EMBED) {
+                        size_t pos_row, out_row;
+                        embed_rows(blk, 0, pos_row, out_row);
+                        ca = C + out_row * p.ldc + nw + (blk & 1) * 32 + ch8 * 4;
+                        embed_rows(blk, 1, pos_row, out_row);
+                        cb = C + out_row * p.ldc + nw + (blk & 1) * 32 + ch8 * 4;
+                    }
+                    if (INTERIOR || in_range(blk, 0)) *reinterpret_cast<f32x4 *>(ca) = ya;
+                    if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cb) = yb;
                     coff += (blk & 1) ? 2 * c8 - 32 : 32;
                     asm volatile("" : "+v"(coff));
                     if (blk + 1 < NB) get(blk + 1, va, vb);
@@ -484,12 +519,14 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][2 + j] = PP_MFMA(wq1[j][ks], xq[i][ks], acc[i][2 + j], 0, 0, 0);
+            if (ks == 0) prepare_next();  // scalar work under the matrix pipe
+        }
         __builtin_amdgcn_s_setprio(0);
         PP_STAMP(8);
         PP_BARRIER();
@@ -631,6 +668,7 @@ int launch_gemm_bf16_pp(hipStream_t s, const Bf16Params &p, int epilogue, int cu
         case VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL>, grid, block, 0, s, p); break;
+        case VITHIP_BF16_EPI_F32_EMBED: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_EMBED>, grid, block, 0, s, p); break;
         case 201: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 1>), grid, block, 0, s, p); break;
         case 202: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 2>), grid, block, 0, s, p); break;
         case 203: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 3>), grid, block, 0, s, p); break;

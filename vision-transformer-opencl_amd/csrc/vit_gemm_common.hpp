@@ -241,6 +241,7 @@ struct Bf16Params {
     int M, N, K;
     int tiles_m, tiles_n, group_m;
     unsigned long long *dbg;  // stamped probe build only
+    int patches;              // F32_EMBED epilogue: patches per image
     int stagger;              // ping-pong kernel: start-up skew between workgroups, in units of 512 cycles
 };
 int launch_gemm_bf16_pp(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);

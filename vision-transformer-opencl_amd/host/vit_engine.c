@@ -273,12 +273,14 @@ int vit_engine_load_weights(vit_engine *e, const Network *weights, int count) {
         /* bf16 copies of the four GEMM weights of every layer (in_proj, out_proj, fc1, fc2), converted on
          * the device from the rounded fp32 upload (round to nearest even); everything else stays fp32 */
         static const int gemm_slots[4] = {2, 4, 8, 10};
-        size_t total16 = 0;
+        size_t total16 = (weights[1].size + 63) & ~(size_t)63;   /* conv_proj weight: patch embedding on the bf16 pipe */
         for (int l = 0; l < e->cfg.depth; ++l)
             for (int k = 0; k < 4; ++k) total16 += (weights[4 + VIT_WEIGHTS_PER_LAYER * l + gemm_slots[k]].size + 63) & ~(size_t)63;
         if (e->wblob16) { vithip_free(e->wblob16); e->wblob16 = NULL; }
         HIP_TRY(e, vithip_malloc((void **)&e->wblob16, total16 * sizeof(unsigned short)));
-        size_t off16 = 0;
+        size_t off16 = (weights[1].size + 63) & ~(size_t)63;
+        e->w16[1] = e->wblob16;
+        HIP_TRY(e, vithip_f32_to_bf16(e->stream, e->w[1], e->w16[1], weights[1].size));
         for (int l = 0; l < e->cfg.depth; ++l)
             for (int k = 0; k < 4; ++k) {
                 const int idx = 4 + VIT_WEIGHTS_PER_LAYER * l + gemm_slots[k];
@@ -383,13 +385,22 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
 
 #define LANES for (int j = 0; j < L; ++j)
 #define ROWS(j) ((size_t)lane[j].off * T)
+    const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
+    /* bf16 patch embedding needs K = chans*patch^2 to be a multiple of 64 (two K steps at least) and patch % 8 == 0;
+     * its bf16 patch rows live in the (still unused) hidden-layer buffer */
+    const int pk = c->in_chans * c->patch_size * c->patch_size;
+    const int embed16 = bf16 && pk % 64 == 0 && pk >= 128 && c->patch_size % 8 == 0 && (size_t)pk <= 2 * (size_t)H;
     LANES {
         HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_EMBED));
-        HIP_TRY(e, vithip_patch_embed_f32(lane[j].s, d_images + lane[j].off * img, w[1], w[2], w[0], w[3],
-                                          e->x + ROWS(j) * D, lane[j].n, c->img_size, c->patch_size, c->in_chans, D));
+        if (embed16)
+            HIP_TRY(e, vithip_patch_embed_bf16(lane[j].s, d_images + lane[j].off * img, e->w16[1], w[2], w[0], w[3],
+                                               e->x + ROWS(j) * D, (unsigned short *)e->hbuf + (size_t)lane[j].off * (T - 1) * pk,
+                                               lane[j].n, c->img_size, c->patch_size, c->in_chans, D));
+        else
+            HIP_TRY(e, vithip_patch_embed_f32(lane[j].s, d_images + lane[j].off * img, w[1], w[2], w[0], w[3],
+                                              e->x + ROWS(j) * D, lane[j].n, c->img_size, c->patch_size, c->in_chans, D));
         HIP_TRY(e, stage_end(e, lane[j].s));
     }
-    const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
     /* bf16 variant: LN output, qkv, attention output and the MLP hidden layer are bf16 (they live in the same
      * allocations, half used); the residual stream x, LayerNorm statistics, softmax and every accumulation
      * stay fp32; patch embedding and the classifier head run the fp32 kernels. */
