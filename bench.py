@@ -192,8 +192,10 @@ def main() -> None:
     peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
     for stage, rec in times["stages"].items():
         k = STAGE_KERNEL[stage]
+        if args.dtype == "bf16" and stage == "embed":
+            k = "gemm_bf16_pp_kernel<F32_EMBED>"
         if args.dtype == "bf16" and stage in ("qkv", "outproj", "fc1", "fc2"):
-            k = "gemm_bf16_nt_kernel<%s>" % {"qkv": "BF16", "fc1": "BF16_GELU", "outproj": "F32_RESIDUAL", "fc2": "F32_RESIDUAL"}[stage]
+            k = "gemm_bf16_pp_kernel<%s>" % {"qkv": "BF16", "fc1": "BF16_GELU", "outproj": "F32_RESIDUAL", "fc2": "F32_RESIDUAL"}[stage]
         d = per_kernel.setdefault(k, {"ms": 0.0, "launches": 0, "flop": 0.0})
         d["ms"] += rec["ms"]
         d["launches"] += rec["launches"]

@@ -34,6 +34,9 @@ if [ "$2" != "f32only" ]; then
     pmc bf16_fetch FETCH_SIZE --dtype bf16 --batch 2048
     pmc bf16_write WRITE_SIZE --dtype bf16 --batch 2048
     python3 tools/pmc_summary.py "$W/bf16_fetch" "$W/bf16_write" "$OUT/hbm_traffic_pmc_bf16" 2048
+    # BASELINE.json configs[4]: ViT-L/16-384, batch 1024, bf16 (no profiler)
+    timeout -k 10 500 python3 bench.py --no-cpu-baseline --model l16_384 --dtype bf16 --batch 1024 --steps 3 --warmup 1 \
+        > "$OUT/bench_bf16_l16_384_batch1024.json" 2> "$W/l16.err"
 fi
 # the unprofiled headline run, with the CPU baseline and the parity block
 timeout -k 10 500 python3 bench.py > "$OUT/bench_f32_default_unprofiled.json" 2> "$W/unprofiled.err"

@@ -49,7 +49,7 @@ def short_name(name):
 
 
 EPI = {"0": "EPI_BIAS", "1": "EPI_BIAS_GELU", "2": "EPI_BIAS_RESIDUAL"}
-EPI16 = {"0": "BF16", "1": "BF16_GELU", "2": "F32_RESIDUAL"}
+EPI16 = {"0": "BF16", "1": "BF16_GELU", "2": "F32_RESIDUAL", "3": "F32_EMBED"}
 
 
 def bench_key(short):
@@ -62,7 +62,7 @@ def bench_key(short):
         return f"{base}<{EPI.get(targs[4], targs[4])}>"
     if base == "gemm_f32_nt_kernel":
         return f"{base}<A_PATCHES>" if targs[5] == "1" else f"{base}<{EPI.get(targs[4], targs[4])}>"
-    if base == "gemm_bf16_nt_kernel":
+    if base in ("gemm_bf16_nt_kernel", "gemm_bf16_pp_kernel"):
         return f"{base}<{EPI16.get(targs[0], targs[0])}>"
     return base
 
