@@ -11,9 +11,10 @@ the end of each step (the only exchange the north star asks for).  One JSON line
 Extra objects in the line:
   roofline      the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs per launch / average launch
                 duration from HIP events recorded on the launch stream during the timed steps.
-  cpu_baseline  the CPU oracle (bit-identical restatement of the reference's ViT_seq.c) timed on one
-                host core on one image of the same batch; the GPU row for that image is checked
-                against it (1e-4 on probabilities, same top-1).
+  cpu_baseline  the reference's own ViT_seq() (oracle/_ref, compiled from its ViT_seq.c) when that library is
+                present, else the CPU oracle (bit-identical restatement), timed on one host core on one
+                image of the same batch; the GPU row for that image is checked against it (1e-4 on
+                probabilities, same top-1); all_cores = one single-threaded forward per core.
 """
 from __future__ import annotations
 
@@ -52,6 +53,21 @@ def pmc_traffic(kernel, dtype, batch):
     if rec.get("batch") != batch:
         return None
     return rec["kernels"].get(kernel)
+
+
+def quiet_stdout(fn):
+    """Run fn() with file descriptor 1 pointed at /dev/null (C code that printf()s), flushing C stdio before restoring."""
+    import ctypes
+    sys.stdout.flush()
+    saved, devnull = os.dup(1), os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        return fn()
+    finally:
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
 
 
 def stage_macs(cfg, batch):
@@ -236,6 +252,21 @@ def main() -> None:
                   "tolerance": 1e-4 if args.dtype == "f32" else 2e-2}
         cpu = {"value": round(1.0 / cpu_dt, 5), "unit": "images/sec", "cores": args.cpu_threads, "kind": "port",
                "sample": f"image 0 of the batch (1 of {B}), {cpu_dt:.2f} s, oracle/vit_cpu_ref.c gcc -O2 -ffp-contract=off"}
+        if args.model == "b16" and os.path.exists(po.REF_PATH):
+            # the reference's own ViT_seq() (oracle/_ref, compiled from /root/reference/ViT_seq.c by oracle/Makefile in
+            # the build container; the .so travels, the sources do not) on the same image: it becomes the baseline
+            # ("reference"), the port's time stays beside it, and the GPU row is checked against it as well
+            def run_ref():
+                t = time.perf_counter()
+                out = po.Reference().vit_seq([host_imgs[0]], weights)
+                return out, time.perf_counter() - t
+            ref_probs, ref_dt = quiet_stdout(run_ref)   # ViT_seq printf()s its own timing: keep stdout to one JSON line
+            cpu = {"value": round(1.0 / ref_dt, 5), "unit": "images/sec", "cores": 1, "kind": "reference",
+                   "sample": f"image 0 of the batch (1 of {B}), {ref_dt:.2f} s in the reference's ViT_seq() (ViT_seq.c gcc -O2 "
+                             "-ffp-contract=off, oracle/_ref/libvitseq_ref.so)",
+                   "port": {"value": round(1.0 / cpu_dt, 5), "seconds": round(cpu_dt, 2), "bit_identical_to_reference":
+                            bool(np.array_equal(ref_probs[0], ref_p))}}
+            parity["max_abs_prob_err_vs_reference"] = float(np.abs(got - ref_probs[0]).max())
         if args.cpu_threads == 1 and not args.no_cpu_all_cores:
             # the reference is single-threaded, so the honest "all cores" figure is one independent
             # single-threaded forward per core, run concurrently (ctypes releases the GIL; the oracle has no shared state)
