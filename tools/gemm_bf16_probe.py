@@ -28,7 +28,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "stagger":
             out[name] = round(2.0 * M_ * N * K / (min(ms) * 1e-3) / 1e12, 1)
             for d in (dA, dW, db, dC):
                 d.free()
-        print(json.dumps({"stagger": st, "tflops": out}))
+        print(json.dumps({sys.argv[2]: st, "tflops": out}))
     L.vithip_gemm_bf16_set_stagger(0)
     B.gemm_bf16_set_variant(0)
     sys.exit(0)

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             // cycles per tile measured).  So they are inline asm with counted waits (vmcnt retires in issue order):
             // one block (2 loads) per batch, four batches in flight.  Counted waits need every load and store to be
             // issued, so only tiles fully inside the matrix take that path; edge tiles predicate and wait for all.
-            constexpr int NB = 16, AHEAD = 4;
+            constexpr int NB = 16, AHEAD = EPI == VITHIP_BF16_EPI_F32_EMBED ? 2 : 4;  // pos_emb is cache-resident: short look-ahead, fewer registers
             f32x4 res[AHEAD][2];
             // running pointers (block order: (i, pj) = (0,0) (0,1) (1,0) ...; inside a block rows +0 and +8)
             const float *rbase = p.R + (size_t)(mw + row8) * p.ldr + nw + ch8 * 4;
@@ -289,13 +289,25 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                 return (blk >> 1) * 16 + ab * 8 < m_left && (blk & 1) * 32 < n_left;
             };
             // F32_EMBED (patch embedding): GEMM row m = image * P + patch goes to token row m + image + 1 of x (row 0 of
-            // every image is the class token), and the "residual" is pos_emb row patch + 1 (ViT_seq.c:52-101).
-            [[maybe_unused]] auto embed_rows = [&](int blk, int ab, size_t &pos_row, size_t &out_row) __attribute__((always_inline)) {
-                const int m = mw + (blk >> 1) * 16 + ab * 8 + row8;
-                const int im = m / p.patches, pp = m - im * p.patches;
-                pos_row = (size_t)pp + 1;
-                out_row = (size_t)m + im + 1;
+            // every image is the class token), and the "residual" is pos_emb row patch + 1 (ViT_seq.c:52-101).  Two
+            // running (patch, image) cursors, one for the look-ahead loads and one for the stores, advanced by 8 rows at
+            // a time -- one division per tile instead of 64 hoisted ones.
+            struct RowCursor { int pp, im; };
+            [[maybe_unused]] auto step8 = [&](RowCursor c) __attribute__((always_inline)) {
+                c.pp += 8;
+                while (c.pp >= p.patches) {
+                    c.pp -= p.patches;
+                    ++c.im;
+                }
+                return c;
             };
+            [[maybe_unused]] RowCursor lcur{0, 0}, scur{0, 0};
+            if constexpr (EPI == VITHIP_BF16_EPI_F32_EMBED) {
+                const int m = mw + row8;
+                lcur.im = m / p.patches;
+                lcur.pp = m - lcur.im * p.patches;
+                scur = lcur;
+            }
             auto load_res = [&](int blk, auto interior_c) __attribute__((always_inline)) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
 #pragma unroll
@@ -303,9 +315,8 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
                     const float *ptr = rbase + roff + ab * r8;
                     if constexpr (EPI == VITHIP_BF16_EPI_F32_EMBED) {
-                        size_t pos_row, out_row;
-                        embed_rows(blk, ab, pos_row, out_row);
-                        ptr = p.R + pos_row * p.ldr + nw + (blk & 1) * 32 + ch8 * 4;
+                        const RowCursor c = ab ? step8(lcur) : lcur;
+                        ptr = p.R + (size_t)(c.pp + 1) * p.ldr + nw + (blk & 1) * 32 + ch8 * 4;
                     }
                     if constexpr (INTERIOR) {
                         // asynchronous: the value is only valid after the counted wait below.  Safe only in straight-line
@@ -318,6 +329,10 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                 }
                 roff += (blk & 1) ? 2 * r8 - 32 : 32;  // next block: other column pair, or the next m-tile
                 asm volatile("" : "+v"(roff));
+                if constexpr (EPI == VITHIP_BF16_EPI_F32_EMBED) {
+                    if (blk & 1) lcur = step8(step8(lcur));
+                    asm volatile("" : "+v"(lcur.pp), "+v"(lcur.im));
+                }
             };
             auto put_blk = [&](int blk) __attribute__((always_inline)) {
                 const int i = blk >> 1, pj = blk & 1;
@@ -356,11 +371,12 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     const f32x4 yb = __builtin_bit_cast(f32x4, vb) + res[blk % AHEAD][1];
                     float *ca = cbase + coff, *cb = cbase + coff + c8;
                     if constexpr (EPI == VITHIP_BF16_EPI_F32_EMBED) {
-                        size_t pos_row, out_row;
-                        embed_rows(blk, 0, pos_row, out_row);
-                        ca = C + out_row * p.ldc + nw + (blk & 1) * 32 + ch8 * 4;
-                        embed_rows(blk, 1, pos_row, out_row);
-                        cb = C + out_row * p.ldc + nw + (blk & 1) * 32 + ch8 * 4;
+                        const RowCursor c1 = step8(scur);
+                        const int mrow = mw + (blk >> 1) * 16 + row8;
+                        ca = C + (size_t)(mrow + scur.im + 1) * p.ldc + nw + (blk & 1) * 32 + ch8 * 4;
+                        cb = C + (size_t)(mrow + 8 + c1.im + 1) * p.ldc + nw + (blk & 1) * 32 + ch8 * 4;
+                        if (blk & 1) scur = step8(c1);
+                        asm volatile("" : "+v"(scur.pp), "+v"(scur.im));
                     }
                     if (INTERIOR || in_range(blk, 0)) *reinterpret_cast<f32x4 *>(ca) = ya;
                     if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cb) = yb;
@@ -375,6 +391,9 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                 run(std::true_type{});
             else
                 run(std::false_type{});
+            // (Tried: touching the next tile's residual lines from here, one dword per 128-B line, so that the next
+            // epilogue's reads hit the caches.  vmcnt retires in order, so the first counted wait after the slack window
+            // also waits for those prefetches: out_proj 646 -> 554-577 TFLOP/s, fc2 1020 -> 957.  Removed.)
         } else {
             bf16_t *C = static_cast<bf16_t *>(p.C);
             // Blocks: m-tile i = 16 rows x 64 bf16; paired mapping: accumulators (i, 2k), (i, 2k+1) of a lane are
