@@ -408,34 +408,62 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
 // from matrix-bound into HBM-bound (2.5 GB of qkv/out per layer at batch 2048):
 //   * K of the head sits in LDS as bf16 rows of 128 B with the GEMM's XOR swizzle (conflict-free
 //     ds_read_b128 of the A fragments);
-//   * V sits TRANSPOSED (Vt[d][key], 456-B rows: conflict-free ds_read_b64), because the P.V product
-//     needs, per lane, 8 keys of one d as its A fragment;
+//   * V sits row-major like K (128-B rows, 16-B chunk c of row k at c ^ 4*((k>>1)&1)); the P.V product needs, per
+//     lane, 8 keys of ONE d as its A fragment, which gfx950's transposing LDS read delivers directly:
+//     ds_read_b64_tr_b16 hands lane i of every 16-lane group column i of a 4-key x 16-d block.  (The first version
+//     transposed V while staging, 32 two-byte LDS stores per thread: a quarter of the kernel.)
 //   * P goes from the S^T accumulator to the B operand of P.V in registers: registers 8s..8s+7 of a
 //     32x32 accumulator, packed to bf16, are exactly the k-step-s fragment whose element j of lane half h
 //     is key 16s + 8(j>>2) + 4h + (j&3) -- the V^T fragment is gathered in that same order.
 // Softmax, max and sums are fp32; P is rounded to bf16 once (the documented cost of the bf16 variant).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-constexpr int VT_LD = 228;  // Vt row length in bf16 (224 keys + 4): 456 B = 114 dwords, 114 % 64 = 50 -> conflict-free b64
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4v lds_short4v;
 
+// A fragment of O^T = V^T . P^T for d-tile dt and the 16 keys starting at key16 (a multiple of 16), in the key order
+// of the P fragment: element j of lane half h is key key16 + 8(j>>2) + 4h + (j&3).  Vs: [keys][64] bf16, swizzled as
+// above.  Per 16-lane group the transposing read takes a block of 4 keys x 16 d: lane 4q+p of the group supplies the
+// address of key row q, d columns 4p..4p+3, lane i receives column i.  EXEC must be all ones (wave-uniform callers).
+__device__ __forceinline__ bf16x8 v_fragment_tr(const bf16_t *Vs, int key16, int dt, int lane) {
+    const int h = lane >> 5, g2 = (lane >> 4) & 1, q = (lane & 15) >> 2, pq = lane & 3;
+    const int row = key16 + 4 * h + q;                     // (row >> 1) & 1 == (q >> 1) & 1: key16 + 4h is a multiple of 4
+    const int chunk = (dt * 4 + 2 * g2 + (pq >> 1)) ^ (4 * ((q >> 1) & 1));
+    const bf16_t *ptr = Vs + row * HD + chunk * 8 + 4 * (pq & 1);
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)ptr);
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)(ptr + 8 * HD));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+// Persistent: a workgroup walks (image, head) items; the K/V rows and the Q fragments of the NEXT item are fetched
+// into registers before the products of the current one, so the HBM round trip that used to open every workgroup
+// (one workgroup per CU fits: 164 VGPRs) hides under the matrix and softmax work.
 template <int NKT>
 __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_t *__restrict__ qkv,
-                                                                     bf16_t *__restrict__ out, int tokens, int heads) {
+                                                                     bf16_t *__restrict__ out, int tokens, int heads,
+                                                                     int items) {
     constexpr int KEYS = NKT * 32;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[KEYS * HD + HD * VT_LD];
-    bf16_t *const Ks = lds;                 // [KEYS][64], chunk-swizzled
-    bf16_t *const Vt = lds + KEYS * HD;     // [64][VT_LD]
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * KEYS * HD];
+    bf16_t *const Ks = lds;                 // [KEYS][64], chunk-swizzled for row reads
+    bf16_t *const Vs = lds + KEYS * HD;     // [KEYS][64], chunk-swizzled for transposing reads
 
-    const int head = blockIdx.x, img = blockIdx.y;
     const int D = heads * HD, ld = 3 * D;
     const int tid = threadIdx.x;
-    const bf16_t *base = qkv + (size_t)img * tokens * ld + head * HD;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nqt = (tokens + 31) >> 5;
+    const int q0 = wave * 32;
+    const bool computes = wave < nqt;  // wave-uniform
 
-    // ---- stage K (swizzled rows) and V (transposed); everything past `tokens` is zero -------------
-    {
-        const int c8 = tid & 7;                  // 16-B chunk (8 bf16) of a 128-B row
-        constexpr int ROWS_PER_PASS = ATT_THREADS / 8;  // 64
-        constexpr int PASSES = (KEYS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-        uint4 kreg[PASSES], vreg[PASSES];
+    const int c8 = tid & 7;                          // 16-B chunk (8 bf16) of a 128-B row
+    constexpr int ROWS_PER_PASS = ATT_THREADS / 8;   // 64
+    constexpr int PASSES = (KEYS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    uint4 kreg[PASSES], vreg[PASSES];
+    bf16x8 qf[4];
+    auto item_base = [&](int item) { return qkv + (size_t)(item / heads) * tokens * ld + (item % heads) * HD; };
+    auto fetch = [&](int item) {  // K/V rows of the whole head (all threads) + this wave's Q fragments
+        const bf16_t *base = item_base(item);
 #pragma unroll
         for (int it = 0; it < PASSES; ++it) {
             const int row = (tid >> 3) + it * ROWS_PER_PASS;
@@ -444,6 +472,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
             kreg[it] = *reinterpret_cast<const uint4 *>(src + D);
             vreg[it] = *reinterpret_cast<const uint4 *>(src + 2 * D);
         }
+        int qrow = q0 + r;
+        qrow = qrow < tokens ? qrow : tokens - 1;
+        const bf16_t *qsrc = base + (size_t)qrow * ld + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qsrc + ks * 16);
+    };
+
+    int item = blockIdx.x;
+    if (item >= items) return;  // workgroup-uniform
+    fetch(item);
+    for (;;) {
+        // ---- registers -> LDS: K (swizzled rows) and V (rows, transposing-read swizzle); rows past `tokens` are zero
 #pragma unroll
         for (int it = 0; it < PASSES; ++it) {
             const int row = (tid >> 3) + it * ROWS_PER_PASS;
@@ -452,117 +492,101 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
                 const uint4 zero = {0u, 0u, 0u, 0u};
                 const uint4 kv = ok ? kreg[it] : zero, vv = ok ? vreg[it] : zero;
                 *reinterpret_cast<uint4 *>(Ks + row * HD + ((c8 ^ ((row >> 1) & 7)) * 8)) = kv;
-                const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+                *reinterpret_cast<uint4 *>(Vs + row * HD + ((c8 ^ (4 * ((row >> 1) & 1))) * 8)) = vv;
+            }
+        }
+        bf16x8 qc[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    Vt[(c8 * 8 + 2 * q) * VT_LD + row] = (bf16_t)(w[q] & 0xffffu);
-                    Vt[(c8 * 8 + 2 * q + 1) * VT_LD + row] = (bf16_t)(w[q] >> 16);
+        for (int ks = 0; ks < 4; ++ks) qc[ks] = qf[ks];
+        __syncthreads();
+        const int next = item + gridDim.x;
+        if (next < items) fetch(next);  // in flight during everything below
+
+        if (computes) {
+            // ---- S^T = K . Q^T ------------------------------------------------------------------------
+            f32x16 st[NKT];
+            const int sw = (r >> 1) & 7;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) st[kt][v] = 0.0f;
+                const bf16_t *krow = Ks + (kt * 32 + r) * HD;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + h) ^ sw) & 7) * 8);
+                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qc[ks], st[kt], 0, 0, 0);
                 }
             }
-        }
-    }
-    __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int nqt = (tokens + 31) >> 5;
-    if (wave < nqt) {
-        const int q0 = wave * 32;
-        bf16x8 qf[4];
-        {
-            int qrow = q0 + r;
-            qrow = qrow < tokens ? qrow : tokens - 1;
-            const bf16_t *qsrc = base + (size_t)qrow * ld + h * 8;
+            // ---- row softmax (fp32) ---------------------------------------------------------------------
+            float mx = -INFINITY;
+            const int rem = tokens - (NKT - 1) * 32;
+            const int h4 = 4 * h;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qsrc + ks * 16);
-        }
-
-        // ---- S^T = K . Q^T ------------------------------------------------------------------------
-        f32x16 st[NKT];
-        const int sw = (r >> 1) & 7;
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) st[kt][v] = 0.0f;
-            const bf16_t *krow = Ks + (kt * 32 + r) * HD;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + h) ^ sw) & 7) * 8);
-                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kt], 0, 0, 0);
-            }
-        }
-
-        // ---- row softmax (fp32) ---------------------------------------------------------------------
-        float mx = -INFINITY;
-        const int rem = tokens - (NKT - 1) * 32;
-        const int h4 = 4 * h;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                if (kt == NKT - 1) {
-                    const int kloc = (v & 3) + 8 * (v >> 2);
-                    st[kt][v] = h4 < rem - kloc ? st[kt][v] : -INFINITY;
-                }
-                mx = fmaxf(mx, st[kt][v]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        constexpr float kScale = 0.125f * 1.4426950408889634f;
-        const float mxs = -mx * kScale;
-        float sum = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
-                st[kt][v] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-
-        // ---- O^T = V^T . P^T --------------------------------------------------------------------------
-        f32x16 o[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) o[dt][v] = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                if (kt < NKT - 1 || kt * 32 + 16 * s2 < tokens) {  // wave-uniform: skip 16-key blocks past the end
-                    bf16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][8 * s2 + j];
-                    const int key0 = kt * 32 + 16 * s2 + 4 * h;  // keys key0..+3 and key0+8..+11
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const bf16_t *vrow = Vt + (dt * 32 + r) * VT_LD + key0;
-                        const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
-                        const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 8);
-                        const uint4 packed = {lo.x, lo.y, hi.x, hi.y};
-                        const bf16x8 vf = __builtin_bit_cast(bf16x8, packed);
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                for (int v = 0; v < 16; ++v) {
+                    if (kt == NKT - 1) {
+                        const int kloc = (v & 3) + 8 * (v >> 2);
+                        st[kt][v] = h4 < rem - kloc ? st[kt][v] : -INFINITY;
                     }
+                    mx = fmaxf(mx, st[kt][v]);
                 }
-            }
-        }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            constexpr float kScale = 0.125f * 1.4426950408889634f;
+            const float mxs = -mx * kScale;
+            float sum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
+                    st[kt][v] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
 
-        if (q0 + r < tokens) {
-            bf16_t *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+            // ---- O^T = V^T . P^T --------------------------------------------------------------------------
+            f32x16 o[2];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 w;
-                    w[0] = o[dt][4 * g + 0] * inv;
-                    w[1] = o[dt][4 * g + 1] * inv;
-                    w[2] = o[dt][4 * g + 2] * inv;
-                    w[3] = o[dt][4 * g + 3] * inv;
-                    store4<bf16_t>(dst + dt * 32 + 8 * g, w);
+                for (int v = 0; v < 16; ++v) o[dt][v] = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (kt < NKT - 1 || kt * 32 + 16 * s2 < tokens) {  // wave-uniform: skip 16-key blocks past the end
+                        bf16x8 pf;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][8 * s2 + j];
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_fragment_tr(Vs, kt * 32 + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
+                    }
                 }
+            }
+
+            if (q0 + r < tokens) {
+                const int img = item / heads, head = item % heads;
+                bf16_t *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 w;
+                        w[0] = o[dt][4 * g + 0] * inv;
+                        w[1] = o[dt][4 * g + 1] * inv;
+                        w[2] = o[dt][4 * g + 2] * inv;
+                        w[3] = o[dt][4 * g + 3] * inv;
+                        store4<bf16_t>(dst + dt * 32 + 8 * g, w);
+                    }
+            }
         }
+        if (next >= items) break;
+        item = next;
+        __syncthreads();  // everybody is done with this item's K/V before they are overwritten
     }
 }
 
@@ -571,9 +595,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
 __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(const bf16_t *__restrict__ qkv,
                                                                              bf16_t *__restrict__ out, int tokens,
                                                                              int heads) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[CKEYS * HD + HD * VT_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * CKEYS * HD];
     bf16_t *const Ks = lds;
-    bf16_t *const Vt = lds + CKEYS * HD;
+    bf16_t *const Vs = lds + CKEYS * HD;
 
     const int head = blockIdx.x, img = blockIdx.y;
     const int D = heads * HD, ld = 3 * D;
@@ -601,42 +625,43 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(con
     constexpr float kScale = 0.125f * 1.4426950408889634f;
     const int h4 = 4 * h, sw = (r >> 1) & 7;
 
+    // the K/V rows of chunk ch+1 are fetched into registers while chunk ch is multiplied (one workgroup per CU fits,
+    // so nothing else hides that HBM round trip)
     const int nchunks = (tokens + CKEYS - 1) / CKEYS;
+    const int c8 = tid & 7;
+    constexpr int ROWS_PER_PASS = ATT_THREADS / 8;
+    constexpr int PASSES = (CKEYS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    uint4 kreg[PASSES], vreg[PASSES];
+    auto fetch = [&](int ch) {
+        const int key_base = ch * CKEYS;
+        const int ckeys = tokens - key_base < CKEYS ? tokens - key_base : CKEYS;
+#pragma unroll
+        for (int it = 0; it < PASSES; ++it) {
+            const int row = (tid >> 3) + it * ROWS_PER_PASS;
+            const int srow = key_base + (row < ckeys ? row : ckeys - 1);
+            const bf16_t *src = base + (size_t)srow * ld + c8 * 8;
+            kreg[it] = *reinterpret_cast<const uint4 *>(src + D);
+            vreg[it] = *reinterpret_cast<const uint4 *>(src + 2 * D);
+        }
+    };
+    fetch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int key_base = ch * CKEYS;
         const int ckeys = tokens - key_base < CKEYS ? tokens - key_base : CKEYS;
         if (ch > 0) __syncthreads();
-        {
-            const int c8 = tid & 7;
-            constexpr int ROWS_PER_PASS = ATT_THREADS / 8;
-            constexpr int PASSES = (CKEYS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-            uint4 kreg[PASSES], vreg[PASSES];
 #pragma unroll
-            for (int it = 0; it < PASSES; ++it) {
-                const int row = (tid >> 3) + it * ROWS_PER_PASS;
-                const int srow = key_base + (row < ckeys ? row : ckeys - 1);
-                const bf16_t *src = base + (size_t)srow * ld + c8 * 8;
-                kreg[it] = *reinterpret_cast<const uint4 *>(src + D);
-                vreg[it] = *reinterpret_cast<const uint4 *>(src + 2 * D);
-            }
-#pragma unroll
-            for (int it = 0; it < PASSES; ++it) {
-                const int row = (tid >> 3) + it * ROWS_PER_PASS;
-                if (row < CKEYS) {
-                    const bool ok = row < ckeys;
-                    const uint4 zero = {0u, 0u, 0u, 0u};
-                    const uint4 kv = ok ? kreg[it] : zero, vv = ok ? vreg[it] : zero;
-                    *reinterpret_cast<uint4 *>(Ks + row * HD + ((c8 ^ ((row >> 1) & 7)) * 8)) = kv;
-                    const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        Vt[(c8 * 8 + 2 * q) * VT_LD + row] = (bf16_t)(w[q] & 0xffffu);
-                        Vt[(c8 * 8 + 2 * q + 1) * VT_LD + row] = (bf16_t)(w[q] >> 16);
-                    }
-                }
+        for (int it = 0; it < PASSES; ++it) {
+            const int row = (tid >> 3) + it * ROWS_PER_PASS;
+            if (row < CKEYS) {
+                const bool ok = row < ckeys;
+                const uint4 zero = {0u, 0u, 0u, 0u};
+                const uint4 kv = ok ? kreg[it] : zero, vv = ok ? vreg[it] : zero;
+                *reinterpret_cast<uint4 *>(Ks + row * HD + ((c8 ^ ((row >> 1) & 7)) * 8)) = kv;
+                *reinterpret_cast<uint4 *>(Vs + row * HD + ((c8 ^ (4 * ((row >> 1) & 1))) * 8)) = vv;
             }
         }
         __syncthreads();
+        if (ch + 1 < nchunks) fetch(ch + 1);
         if (!active) continue;
 
         f32x16 st[CKT];
@@ -695,15 +720,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(con
                     bf16x8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][8 * s2 + j];
-                    const int key0 = kt * 32 + 16 * s2 + 4 * h;
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const bf16_t *vrow = Vt + (dt * 32 + r) * VT_LD + key0;
-                        const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
-                        const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 8);
-                        const uint4 packed = {lo.x, lo.y, hi.x, hi.y};
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, packed), pf, o[dt], 0, 0, 0);
-                    }
+                    for (int dt = 0; dt < 2; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_fragment_tr(Vs, kt * 32 + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
                 }
             }
         }
@@ -728,7 +747,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(con
 
 template <int NKT>
 int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads) {
-    hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads);
+    const int items = heads * n_images;
+    static int cus = 0;  // CU count, queried once
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return static_cast<int>(hipErrorInvalidDevice);
+    }
+    const int per_cu = NKT <= 3 ? 2 : 1;  // VGPR-limited residency (8 waves per workgroup)
+    const int grid = items < cus * per_cu ? items : cus * per_cu;
+    hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(grid), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads, items);
     return static_cast<int>(hipGetLastError());
 }
 
