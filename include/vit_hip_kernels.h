@@ -117,9 +117,12 @@ typedef struct {
     int M, N, K;                        /* K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0 */
     int epilogue;
 } vithip_gemm_bf16_args;
-/* C = epilogue(A . W^T + bias) on v_mfma_f32_32x32x16_bf16, fp32 accumulate. */
+/* C = epilogue(A . W^T + bias) on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16 in the ping-pong kernel,
+ * v_mfma_f32_32x32x16_bf16 in the two-stage one), fp32 accumulate.  BF16_GELU rounds gelu(acc + bias) to bf16 (a
+ * polynomial erfc whose error stays below 5 % of half a bf16 ulp); F32_RESIDUAL adds an fp32 residual in fp32. */
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
-/* tuning/testing: 0 auto (default), 1 two-stage kernel (vit_gemm_bf16.hip), 2 ping-pong kernel (vit_gemm_bf16_pp.hip) */
+/* tuning/testing: 0 auto (default: ping-pong kernel whenever K >= 128), 1 two-stage kernel (vit_gemm_bf16.hip),
+ * 2 ping-pong kernel (vit_gemm_bf16_pp.hip; invalid-value error when K < 128); 3, 4 = its instrumented probe builds */
 int vithip_gemm_bf16_set_variant(int variant);
 /* tuning: start-up skew between the persistent workgroups of the ping-pong kernel, units of 512 cycles per
  * position inside the XCD (0..64) */
@@ -128,13 +131,14 @@ int vithip_gemm_bf16_set_stagger(int units);
 int vithip_gemm_bf16_set_max_workgroups(int n);
 /* probe only: variant 3 = ping-pong kernel with s_memtime stamps (8 waves x 32 u64 of workgroup 0) written to buf */
 int vithip_gemm_bf16_set_debug_buffer(void *buf);
-/* LayerNorm with fp32 statistics and a bf16 store; attention reading bf16 Q/K/V and writing bf16
- * (K/V widened to fp32 in LDS, fp32 MFMA and softmax as vithip_attention_f32). */
+/* LayerNorm with fp32 statistics and a bf16 store; attention reading bf16 Q/K/V [n*tokens][3*heads*64] and
+ * writing bf16 [n*tokens][heads*64]: both products on bf16 MFMA with fp32 softmax (P rounded to bf16 once), or,
+ * after vithip_attention_bf16_set_mfma(0), K/V widened to fp32 in LDS and the fp32 kernel's arithmetic. */
 int vithip_layernorm_f32_bf16out(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *y, size_t ldy,
                                  const float *gamma, const float *beta, int rows, int dim);
 int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
                             int n_images, int tokens, int heads);
-/* 1 (default): tokens <= 224 run both attention products on bf16 MFMA (P rounded to bf16); 0: fp32 MFMA. */
+/* 1 (default): bf16 MFMA products (resident kernel up to 224 tokens, chunked online-softmax kernel beyond); 0: fp32 MFMA. */
 int vithip_attention_bf16_set_mfma(int on);
 /* Patch embedding on the bf16 matrix pipe (same result layout as vithip_patch_embed_f32: x[n][tokens][D] fp32 with
  * class token and pos_emb applied; ViT_seq.c:25-101): the images are cut into bf16 patch rows

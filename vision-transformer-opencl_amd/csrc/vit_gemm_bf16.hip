@@ -1,5 +1,7 @@
 // csrc/vit_gemm_bf16.hip -- bf16 MFMA "NT" GEMM (fp32 accumulate) for the bf16 variant of the forward
-// (BASELINE.json configs[2]: ViT-B/16, batch 2048, bf16 MFMA).
+// (BASELINE.json configs[2]: ViT-B/16, batch 2048, bf16 MFMA): the C-ABI entry points, the
+// patchify kernel of the bf16 patch embedding, and the FIRST GEMM kernel (two LDS stages, one barrier per K step),
+// which now serves K < 128 and as variant 1 for A/B runs; the kernel the engine uses is csrc/vit_gemm_bf16_pp.hip.
 //
 //   C = epilogue(A[M][K] . W[N][K]^T + bias),  A and W bf16 (K contiguous), bias fp32, accumulate fp32.
 //   epilogues:  BF16       C bf16 = acc + bias                      (QKV in_proj)
