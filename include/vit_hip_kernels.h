@@ -124,6 +124,8 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
 /* tuning/testing: 0 auto (default: ping-pong kernel whenever K >= 128), 1 two-stage kernel (vit_gemm_bf16.hip),
  * 2 ping-pong kernel (vit_gemm_bf16_pp.hip; invalid-value error when K < 128); 3, 4 = its instrumented probe builds */
 int vithip_gemm_bf16_set_variant(int variant);
+/* tuning: barrier schedule of the ping-pong kernel: 1 (default) = one barrier per phase and wave, 0 = two */
+int vithip_gemm_bf16_set_sync(int one_barrier);
 /* tuning: start-up skew between the persistent workgroups of the ping-pong kernel, units of 512 cycles per
  * position inside the XCD (0..64) */
 int vithip_gemm_bf16_set_stagger(int units);

@@ -11,9 +11,12 @@ L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(B.CGemmBf16Args)]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 M = batch * 197
 SHAPES = {"qkv": (M, 2304, 768, 0), "outproj": (M, 768, 768, 2), "fc1": (M, 3072, 768, 1), "fc2": (M, 768, 3072, 2)}
-if len(sys.argv) > 2 and sys.argv[2] == "stagger":
-    for st in (0, 1, 2, 3, 4, 6):
-        L.vithip_gemm_bf16_set_stagger(st)
+if len(sys.argv) > 2 and sys.argv[2] in ("stagger", "sync"):
+    for st in ((0, 1, 0, 1) if sys.argv[2] == "sync" else (0, 1, 2, 3, 4, 6)):
+        if sys.argv[2] == "sync":
+            L.vithip_gemm_bf16_set_sync(st)
+        else:
+            L.vithip_gemm_bf16_set_stagger(st)
         B.gemm_bf16_set_variant(2)
         out = {}
         for name, (M_, N, K, epi) in SHAPES.items():
@@ -30,6 +33,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "stagger":
                 d.free()
         print(json.dumps({sys.argv[2]: st, "tflops": out}))
     L.vithip_gemm_bf16_set_stagger(0)
+    L.vithip_gemm_bf16_set_sync(1)
     B.gemm_bf16_set_variant(0)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "probe":  # timing-only builds on the qkv shape: 101 = no DMA in loop, 102 = DMA only

@@ -302,6 +302,7 @@ int g_cus = 0;      // CU count, queried once
 int g_variant = 0;  // 0 auto (ping-pong kernel when its preconditions hold), 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong
 unsigned long long *g_dbg = nullptr;
 int g_stagger = 0;
+int g_sync1 = 1;
 int g_max_wgs = 0;  // probe: cap on persistent workgroups (0 = one per CU)
 
 }  // namespace
@@ -322,6 +323,11 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
 int vithip_gemm_bf16_set_variant(int variant) {
     if (variant < 0 || variant > 4) return static_cast<int>(hipErrorInvalidValue);
     g_variant = variant;
+    return 0;
+}
+
+int vithip_gemm_bf16_set_sync(int one_barrier) {
+    g_sync1 = one_barrier != 0;
     return 0;
 }
 
@@ -370,6 +376,7 @@ int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const u
     p.group_m = 8;
     p.patches = P;
     p.stagger = g_stagger;
+    p.sync1 = g_sync1;
     if (g_cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -395,6 +402,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
     p.stagger = g_stagger;
+    p.sync1 = g_sync1;
     if (g_cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

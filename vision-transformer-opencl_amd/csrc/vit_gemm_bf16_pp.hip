@@ -65,6 +65,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 
 // STAMP: timing-only instrumentation for tools/gemm_bf16_probe.py (workgroup 0 records s_memtime around the
 // sections of K step 3 of its first tile, and around that tile's epilogue; 32 values per wave in p.dbg).
+// Barriers of the phase pipeline.  Two schedules (Bf16Params::sync1):
+//   sync1 = 0: every phase has a barrier after its load section AND after its MFMA section for all waves; group 1
+//              starts one barrier late, so the groups strictly alternate load / MFMA sections.
+//   sync1 = 1: ONE barrier per phase and wave: group 0 after its MFMA sections, group 1 after its load sections.  Between
+//              two barriers group 0 runs [load p, MFMA p] and group 1 [MFMA p-1, load p]: the same pairing of sections,
+//              but nothing forces them to switch at the same moment, and half the barriers.  Every half-tile is still
+//              waited for (counted vmcnt) before a barrier that precedes its first read, and refilled two phases after
+//              its last read, so the LDS-DMA hazards are covered exactly as before.
+#define PP_BARRIER_L()                  \
+    do {                                \
+        if (!sync1 || g == 1) PP_BARRIER(); \
+    } while (0)
+#define PP_BARRIER_M()                  \
+    do {                                \
+        if (!sync1 || g == 0) PP_BARRIER(); \
+    } while (0)
 #define PP_MFMA(a, b, c, x, y, z) (DBG == 2 ? (c) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z))
 #define PP_LDS_FRAG(ptr) (DBG == 3 ? bf16x8{} : *reinterpret_cast<const bf16x8 *>(ptr))
 #define PP_STAMP(idx)                                                                                   \
@@ -109,6 +125,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     const int first = xcd_remap(blockIdx.x, nwg);
     if (first >= total) return;  // workgroup-uniform
     const int nk = p.K / PBK;
+    const bool sync1 = p.sync1 != 0;
     // Identical persistent workgroups started together stay in lock-step: all 256 epilogues (32 MB of stores)
     // hit the L2s at the same moment and every workgroup then waits for its stores to drain (vmcnt is in-order).
     // A start-up skew of p.stagger x 512 cycles per position inside the XCD spreads them over the tile period.
@@ -472,8 +489,8 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     issue(K0{}, 1);
     issue(K1{}, 1);
     wait_loads();  // kinds 0 and 1 of K step 0 have landed (four younger half-tiles may be in flight)
-    PP_BARRIER();
-    if (g == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
+    PP_BARRIER();  // everybody: half-tiles 0 and 1 are visible
+    if (!sync1 && g == 1) PP_BARRIER();  // two-barrier schedule: group 1 runs one barrier behind group 0 from here on
 
     if constexpr (STAMP == 1) stamps[20] = (unsigned)__builtin_amdgcn_s_memtime();
     in_loop = true;
@@ -517,11 +534,11 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         issue(K2{}, par ^ 1);
         wait_loads();
         PP_STAMP(1);
-        PP_BARRIER();
+        PP_BARRIER_L();
         PP_STAMP(2);
         mfma0();
         PP_STAMP(3);
-        PP_BARRIER();
+        PP_BARRIER_M();
         PP_STAMP(4);
     };
     auto phase1 = [&]() __attribute__((always_inline)) {  // quadrant (m0, n1)
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         issue(K3{}, par ^ 1);
         wait_loads();
         PP_STAMP(6);
-        PP_BARRIER();
+        PP_BARRIER_L();
         PP_STAMP(7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         }
         __builtin_amdgcn_s_setprio(0);
         PP_STAMP(8);
-        PP_BARRIER();
+        PP_BARRIER_M();
         PP_STAMP(9);
     };
     auto phase2 = [&]() __attribute__((always_inline)) {  // quadrant (m1, n1)
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         issue(K0{}, par);
         wait_loads();
         PP_STAMP(11);
-        PP_BARRIER();
+        PP_BARRIER_L();
         PP_STAMP(12);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
@@ -574,14 +591,14 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     acc[4 + i][2 + j] = PP_MFMA(wq1[j][ks], xq[i][ks], acc[4 + i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_STAMP(13);
-        PP_BARRIER();
+        PP_BARRIER_M();
         PP_STAMP(14);
     };
     auto phase3 = [&]() __attribute__((always_inline)) {  // quadrant (m1, n0); no fragment reads
         issue(K1{}, par);
         wait_loads();
         PP_STAMP(16);
-        PP_BARRIER();
+        PP_BARRIER_L();
         PP_STAMP(17);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -593,7 +610,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     acc[4 + i][j] = PP_MFMA(wq0[j][ks], xq[i][ks], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_STAMP(18);
-        PP_BARRIER();
+        PP_BARRIER_M();
         PP_STAMP(19);
     };
 
@@ -611,7 +628,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         if (g == 0 && have_prev) {
             issue(K2{}, par ^ 1);
             wait_loads();
-            PP_BARRIER();
+            PP_BARRIER_L();
             epilogue(prev_tile, prev_tpar);
             __builtin_amdgcn_sched_barrier(0);
             reads0();  // after the epilogue: its temporaries and these fragments do not fit together
@@ -619,14 +636,14 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             reads0();
             issue(K2{}, par ^ 1);
             wait_loads();
-            PP_BARRIER();
+            PP_BARRIER_L();
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         mfma0();
-        PP_BARRIER();
+        PP_BARRIER_M();
         phase1();
         phase2();
         phase3();
@@ -661,7 +678,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     }
     if (g == 0) {
         epilogue(prev_tile, prev_tpar);  // group 0's last tile
-        PP_BARRIER();                    // pairs with group 1's last barrier
+        if (!sync1) PP_BARRIER();        // two-barrier schedule: pairs with group 1's last barrier
     }
     if constexpr (STAMP == 1) {
         stamps[23] = (unsigned)__builtin_amdgcn_s_memtime();

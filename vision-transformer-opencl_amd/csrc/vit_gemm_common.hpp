@@ -242,6 +242,7 @@ struct Bf16Params {
     int tiles_m, tiles_n, group_m;
     unsigned long long *dbg;  // stamped probe build only
     int patches;              // F32_EMBED epilogue: patches per image
+    int sync1;                // ping-pong kernel: 1 = one barrier per phase and wave (see PP_BARRIER_L/M)
     int stagger;              // ping-pong kernel: start-up skew between workgroups, in units of 512 cycles
 };
 int launch_gemm_bf16_pp(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);
