@@ -179,3 +179,20 @@ def test_bf16_forward_vit_l_geometry(oracle):
     assert float(np.abs(probs - ref).max()) <= BF16_PROB_TOL
     assert (probs.argmax(1) == ref.argmax(1)).all()
     eng.close()
+
+
+def test_facade_bf16_by_environment():
+    """VIT_HIP_DTYPE=bf16 switches the drop-in ViT_opencl() surface to the bf16 variant (read at initialize time)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vit_b16_e2e.npz"))
+    W = synth.make_weights(synth.VIT_B16, int(g["weight_seed"]))
+    imgs = synth.make_images(synth.VIT_B16, 2, int(g["image_seed"]))
+    os.environ["VIT_HIP_DTYPE"] = "bf16"
+    try:
+        probs = B.facade_forward(imgs, W, use_reference_names=True)
+    finally:
+        del os.environ["VIT_HIP_DTYPE"]
+    ref = g["probs"][:2]
+    assert (probs.argmax(1) == ref.argmax(1)).all()
+    err = float(np.abs(probs - ref).max())
+    assert 1e-5 < err <= 2e-2, err     # within the bf16 bar, and really the bf16 path (fp32 gives ~1e-6)
