@@ -100,6 +100,10 @@ def main() -> None:
                     help="b16 = ViT-B/16 224 (the metric); l16_384 = ViT-L/16 384 (BASELINE.json configs[4], use --dtype bf16 --batch 1024)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the metric configuration (BASELINE.json configs[1]); bf16 = configs[2] (use --batch 2048)")
+    ap.add_argument("--prune-last-layer", action="store_true",
+                    help="NOT the metric configuration: vit_engine_options.prune_last_layer (the last encoder layer computes "
+                         "only the class rows; bit-identical probabilities, 7 %% less arithmetic).  FLOP figures then count "
+                         "the executed work")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
     args = ap.parse_args()
 
@@ -133,7 +137,7 @@ def main() -> None:
     # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
     # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
     eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1), lanes=args.lanes,
-                         dtype=args.dtype)
+                         dtype=args.dtype, prune_last_layer=args.prune_last_layer)
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the
@@ -199,7 +203,11 @@ def main() -> None:
 
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
-    gflop_img = 2.0 * cfg.macs_per_image / 1e9
+    T_, D_, H_, hd_ = cfg.tokens, cfg.embed_dim, cfg.hidden_dim, cfg.embed_dim // cfg.num_heads
+    # MACs per image the pruned last layer does not execute, by stage (vit_config_macs_per_image_pruned)
+    saved = ({"qkv": (T_ - 1) * D_ * D_, "attn": (T_ - 1) * 2 * cfg.num_heads * T_ * hd_, "outproj": (T_ - 1) * D_ * D_,
+              "fc1": (T_ - 1) * D_ * H_, "fc2": (T_ - 1) * D_ * H_} if args.prune_last_layer else {})
+    gflop_img = 2.0 * (cfg.macs_per_image - sum(saved.values())) / 1e9
     model_tflops = value * gflop_img / 1e3 / world  # per GPU
 
     # ---- roofline of the dominant kernel (per-launch, from the stage brackets) -------------------
@@ -215,7 +223,10 @@ def main() -> None:
         d = per_kernel.setdefault(k, {"ms": 0.0, "launches": 0, "flop": 0.0})
         d["ms"] += rec["ms"]
         d["launches"] += rec["launches"]
-        d["flop"] += 2.0 * macs[stage] * rec["launches"]
+        # per step: depth launches of the full size, minus what a pruned last layer skips (its extra small launches
+        # are in rec["launches"] and rec["ms"]; the flops below are the executed ones either way)
+        per_step = {"embed": 1, "head": 1}.get(stage, cfg.depth if stage in macs and macs[stage] else 0)
+        d["flop"] += 2.0 * (macs[stage] * per_step - B * saved.get(stage, 0)) * kernel_steps
     dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = dom["ms"] / max(dom["launches"], 1)
     achieved = dom["flop"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -294,7 +305,7 @@ def main() -> None:
                                     f"{'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} forward, batch {B} per GPU, synthetic weights and images "
                                     "(BASELINE.json configs[%d])" % (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2))),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
-                       "gflop_per_image": round(gflop_img, 4), "device": info["name"], "arch": info["arch"],
+                       "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }))

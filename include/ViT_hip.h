@@ -27,7 +27,8 @@
  *
  * Environment: VIT_HIP_DEVICE (device ordinal, default 0), VIT_HIP_MAX_BATCH (chunk size,
  * default 256), VIT_HIP_LANES (concurrent sub-batches per chunk, default 2), VIT_HIP_DTYPE ("bf16" selects the bf16
- * matrix-pipe variant: same top-1, |dprob| <= 2e-2 against the fp32 reference instead of 1e-4; default fp32).
+ * matrix-pipe variant: same top-1, |dprob| <= 2e-2 against the fp32 reference instead of 1e-4; default fp32),
+ * VIT_HIP_PRUNE_LAST_LAYER (1: vit_engine_options.prune_last_layer, bit-identical probabilities; default 0).
  */
 #ifndef VIT_HIP_H
 #define VIT_HIP_H

@@ -37,6 +37,12 @@ typedef struct {
     int profile;     /* 1: bracket every stage with events and accumulate vit_stage_times */
     int lanes;       /* sub-batches of a chunk run concurrently on separate streams (1..4); default 1 */
     int dtype;       /* VIT_DTYPE_F32 (default: the reference's arithmetic) or VIT_DTYPE_BF16 (bf16 MFMA GEMMs) */
+    int prune_last_layer; /* 1: in the LAST encoder layer compute only what the class token needs (default 0).  Only row
+                           * 0 of the encoder output feeds the classifier (ViT_seq.c:429-435), so after the last layer's
+                           * K/V projections every token-wise operation runs on the n class rows instead of n*tokens:
+                           * the probabilities are bit-identical, 7 % of the reference's arithmetic is not executed
+                           * (vit_config_macs_per_image_pruned).  Off by default: bench.py's metric counts the
+                           * reference's full work.  tokens <= 224. */
 } vit_engine_options;
 
 enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };
@@ -60,6 +66,8 @@ int vit_config_tokens(const vit_config *cfg);
 size_t vit_config_weight_size(const vit_config *cfg, int index);
 /* Algorithmic MACs of one image (17,563,828,224 for ViT-B/16-224). */
 unsigned long long vit_config_macs_per_image(const vit_config *cfg);
+/* MACs actually executed per image with vit_engine_options.prune_last_layer = 1. */
+unsigned long long vit_config_macs_per_image_pruned(const vit_config *cfg);
 
 void vit_engine_default_options(vit_engine_options *opt);
 int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_options *opt);

@@ -140,6 +140,12 @@ int vithip_layernorm_f32_bf16out(vithip_stream_t stream, const float *x, size_t 
                                  const float *gamma, const float *beta, int rows, int dim);
 int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
                             int n_images, int tokens, int heads);
+/* As vithip_attention_f32 / vithip_attention_bf16io, but only the first q_rows query rows of every image are computed
+ * and stored (rows q_rows.. of `out` are left untouched); tokens <= 224.  q_rows = 1 is the class token. */
+int vithip_attention_f32_rows(vithip_stream_t stream, const float *qkv, float *out, int n_images, int tokens, int heads,
+                              int q_rows);
+int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images,
+                                 int tokens, int heads, int q_rows);
 /* 1 (default): bf16 MFMA products (resident kernel up to 224 tokens, chunked online-softmax kernel beyond); 0: fp32 MFMA. */
 int vithip_attention_bf16_set_mfma(int on);
 /* Patch embedding on the bf16 matrix pipe (same result layout as vithip_patch_embed_f32: x[n][tokens][D] fp32 with

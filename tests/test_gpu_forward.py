@@ -198,3 +198,34 @@ def test_empty_and_invalid_inputs(b16):
     L.Release_hip()
     with pytest.raises(B.VitError, match="bad arguments"):
         eng.forward(np.zeros((0, 3, 224, 224), np.float32))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_prune_last_layer_is_bit_identical(dtype):
+    """vit_engine_options.prune_last_layer: the last encoder layer computes only what the class token needs.  Every
+    operator computes its rows independently of how many rows it is given, so probabilities and logits must be
+    IDENTICAL to the full forward, bit for bit (ViT-B/16 golden images plus a batch that spans lanes)."""
+    cfg = synth.VIT_B16
+    W = synth.make_weights(cfg, 1234)
+    imgs = synth.make_images(cfg, 9, 99)
+    outs = []
+    for prune in (False, True):
+        eng = B.Engine(cfg, max_batch=16, lanes=2, dtype=dtype, prune_last_layer=prune)
+        eng.load_weights(W)
+        p = eng.forward(imgs)
+        outs.append((p.copy(), eng.logits(9).copy()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_attention_rows_only_touches_the_requested_rows():
+    """vithip_attention_f32_rows(q_rows = 1): row 0 of every image equals the full attention's row 0, the other rows
+    of the output buffer keep their previous contents."""
+    n, T, heads = 3, 197, 12
+    qkv = synth.uniform(999, 70, n * T * 3 * heads * 64, -1.0, 1.0).reshape(n * T, 3 * heads * 64)
+    full = B.attention(qkv, n, T, heads)
+    got = B.attention_rows(qkv, n, T, heads, 1, fill=7.0)
+    for b in range(n):
+        assert np.array_equal(got[b * T], full[b * T])
+        assert (got[b * T + 1:(b + 1) * T] == 7.0).all()

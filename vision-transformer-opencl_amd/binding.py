@@ -47,7 +47,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
-                ("dtype", C.c_int)]
+                ("dtype", C.c_int), ("prune_last_layer", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -309,6 +309,18 @@ def attention(qkv, n_images: int, tokens: int, heads: int) -> np.ndarray:
     return do.numpy()
 
 
+def attention_rows(qkv, n_images: int, tokens: int, heads: int, q_rows: int, fill: float = 0.0) -> np.ndarray:
+    """vithip_attention_f32_rows: the output buffer is pre-filled with `fill` to show which rows are written."""
+    qkv = _as_f32(qkv)
+    D = heads * 64
+    L = lib()
+    L.vithip_attention_f32_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    dq = DeviceArray.from_numpy(qkv)
+    do = DeviceArray.from_numpy(np.full((n_images * tokens, D), fill, np.float32))
+    hip_check(L.vithip_attention_f32_rows(None, dq.ptr, do.ptr, n_images, tokens, heads, q_rows), "vithip_attention_f32_rows")
+    return do.numpy()
+
+
 def patch_embed(cfg: ModelConfig, images, conv_w, conv_b, cls, pos) -> np.ndarray:
     images = _as_f32(images)
     n = images.shape[0]
@@ -362,11 +374,12 @@ class Engine:
     """vit_engine (include/vit_engine.h): weights resident in HBM, batched forward."""
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
-                 lanes: int = 1, dtype: str = "f32"):
+                 lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
-        opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype])
+        opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
+                       1 if prune_last_layer else 0)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

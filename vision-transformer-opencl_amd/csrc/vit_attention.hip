@@ -59,7 +59,7 @@ int g_attn_bf16_mfma = 1;                  // see vithip_attention_bf16_set_mfma
 template <int NKT, typename IO>  // NKT = number of 32-key tiles: tokens <= 32*NKT; IO = float or bf16 bits
 __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const IO *__restrict__ qkv,
                                                                     IO *__restrict__ out,
-                                                                    int tokens, int heads,
+                                                                    int tokens, int heads, int q_rows,
                                                                     unsigned long long *__restrict__ dbg) {
     // dbg != nullptr (tools/attn_probe.py --stamps): cycle stamps of wave 0 at the phase boundaries
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const IO *__
 
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int nqt = (tokens + 31) >> 5;
+    const int nqt = (q_rows + 31) >> 5;  // q_rows <= tokens: only the first q_rows query rows are computed and stored
 
     // One 32-query block per wave (tokens <= 224 => at most 7 of the 8 waves have work).  No loop
     // over blocks: it would let the compiler hoist ~100 per-key addresses and predicates out of it.
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const IO *__
 
         if (dbg) t4 = __builtin_amdgcn_s_memtime();
         // ---- store: lane owns query q0+r; registers 4g..4g+3 are 4 consecutive d ---------
-        if (q0 + r < tokens) {
+        if (q0 + r < q_rows) {
             IO *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -442,7 +442,7 @@ __device__ __forceinline__ bf16x8 v_fragment_tr(const bf16_t *Vs, int key16, int
 template <int NKT>
 __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_t *__restrict__ qkv,
                                                                      bf16_t *__restrict__ out, int tokens, int heads,
-                                                                     int items) {
+                                                                     int items, int q_rows) {
     constexpr int KEYS = NKT * 32;
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * KEYS * HD];
     bf16_t *const Ks = lds;                 // [KEYS][64], chunk-swizzled for row reads
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int nqt = (tokens + 31) >> 5;
+    const int nqt = (q_rows + 31) >> 5;  // only the first q_rows query rows are computed and stored
     const int q0 = wave * 32;
     const bool computes = wave < nqt;  // wave-uniform
 
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
                 }
             }
 
-            if (q0 + r < tokens) {
+            if (q0 + r < q_rows) {
                 const int img = item / heads, head = item % heads;
                 bf16_t *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
 #pragma unroll
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(con
 }
 
 template <int NKT>
-int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads) {
+int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads, int q_rows) {
     const int items = heads * n_images;
     static int cus = 0;  // CU count, queried once
     if (cus == 0) {
@@ -756,32 +756,33 @@ int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int
     }
     const int per_cu = NKT <= 3 ? 2 : 1;  // VGPR-limited residency (8 waves per workgroup)
     const int grid = items < cus * per_cu ? items : cus * per_cu;
-    hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(grid), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads, items);
+    hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(grid), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads, items, q_rows);
     return static_cast<int>(hipGetLastError());
 }
 
 template <int NKT, typename IO>
-int launch(hipStream_t s, const IO *qkv, IO *out, int n_images, int tokens, int heads) {
+int launch(hipStream_t s, const IO *qkv, IO *out, int n_images, int tokens, int heads, int q_rows) {
     hipLaunchKernelGGL((attention_f32_kernel<NKT, IO>), dim3(heads, n_images), dim3(ATT_THREADS), 0, s, qkv, out,
-                       tokens, heads, g_attn_dbg);
+                       tokens, heads, q_rows, g_attn_dbg);
     return static_cast<int>(hipGetLastError());
 }
 
 template <typename IO>
-int attention_dispatch(hipStream_t s, const IO *qkv, IO *out, int n_images, int tokens, int heads) {
-    if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0) return static_cast<int>(hipErrorInvalidValue);
+int attention_dispatch(hipStream_t s, const IO *qkv, IO *out, int n_images, int tokens, int heads, int q_rows) {
+    if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0 || q_rows <= 0 || q_rows > tokens)
+        return static_cast<int>(hipErrorInvalidValue);
     if ((reinterpret_cast<size_t>(qkv) & 15) || (reinterpret_cast<size_t>(out) & 15))
         return static_cast<int>(hipErrorInvalidValue);
     const int nkt = (tokens + 31) / 32;
     switch (nkt) {
-        case 1: return launch<1, IO>(s, qkv, out, n_images, tokens, heads);
-        case 2: return launch<2, IO>(s, qkv, out, n_images, tokens, heads);
-        case 3: return launch<3, IO>(s, qkv, out, n_images, tokens, heads);
-        case 4: return launch<4, IO>(s, qkv, out, n_images, tokens, heads);
-        case 5: return launch<5, IO>(s, qkv, out, n_images, tokens, heads);
-        case 6: return launch<6, IO>(s, qkv, out, n_images, tokens, heads);
-        case 7: return launch<7, IO>(s, qkv, out, n_images, tokens, heads);
-        default: {  // > 224 tokens: K/V stream through LDS in chunks, online softmax
+        case 1: return launch<1, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
+        case 2: return launch<2, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
+        case 3: return launch<3, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
+        case 4: return launch<4, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
+        case 5: return launch<5, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
+        case 6: return launch<6, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
+        case 7: return launch<7, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
+        default: {  // > 224 tokens: K/V stream through LDS in chunks, online softmax (computes every query row)
             const int qblocks = (nkt + ATT_WAVES - 1) / ATT_WAVES;
             hipLaunchKernelGGL(attention_f32_chunked_kernel<IO>, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s,
                                qkv, out, tokens, heads);
@@ -800,26 +801,49 @@ extern "C" int vithip_attention_set_debug_buffer(void *buf) {
 
 extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
                                     int n_images, int tokens, int heads) {
-    return attention_dispatch<float>(static_cast<hipStream_t>(stream), qkv, out, n_images, tokens, heads);
+    return attention_dispatch<float>(static_cast<hipStream_t>(stream), qkv, out, n_images, tokens, heads, tokens);
 }
 
 // bf16 variant: qkv and out hold bf16 bits; K/V are widened to fp32 while staged into LDS and all
 // arithmetic (fp32 MFMA, softmax) is the same as above; the output is rounded to bf16 once.
+static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images, int tokens,
+                              int heads, int q_rows);
+
 extern "C" int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
                                        int n_images, int tokens, int heads) {
+    return attention_bf16io_q(stream, qkv, out, n_images, tokens, heads, tokens);
+}
+
+// Only the first q_rows query rows of every image (the class token for q_rows = 1; tokens <= 224): used by the engine's
+// exact last-layer pruning -- everything after the last attention depends on row 0 alone.
+extern "C" int vithip_attention_f32_rows(vithip_stream_t stream, const float *qkv, float *out, int n_images, int tokens,
+                                         int heads, int q_rows) {
+    if (tokens > 224) return static_cast<int>(hipErrorInvalidValue);
+    return attention_dispatch<float>(static_cast<hipStream_t>(stream), qkv, out, n_images, tokens, heads, q_rows);
+}
+
+extern "C" int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
+                                            int n_images, int tokens, int heads, int q_rows) {
+    if (tokens > 224) return static_cast<int>(hipErrorInvalidValue);
+    return attention_bf16io_q(stream, qkv, out, n_images, tokens, heads, q_rows);
+}
+
+static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images, int tokens,
+                              int heads, int q_rows) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (q_rows <= 0 || q_rows > tokens) return static_cast<int>(hipErrorInvalidValue);
     if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0 || (reinterpret_cast<size_t>(qkv) & 15) ||
         (reinterpret_cast<size_t>(out) & 15))
         return static_cast<int>(hipErrorInvalidValue);
     if (g_attn_bf16_mfma) {  // bf16 matrix path while K/V of a head fit LDS; longer sequences use the chunked kernel
         switch ((tokens + 31) / 32) {
-            case 1: return launch_bf16<1>(s, qkv, out, n_images, tokens, heads);
-            case 2: return launch_bf16<2>(s, qkv, out, n_images, tokens, heads);
-            case 3: return launch_bf16<3>(s, qkv, out, n_images, tokens, heads);
-            case 4: return launch_bf16<4>(s, qkv, out, n_images, tokens, heads);
-            case 5: return launch_bf16<5>(s, qkv, out, n_images, tokens, heads);
-            case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads);
-            case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads);
+            case 1: return launch_bf16<1>(s, qkv, out, n_images, tokens, heads, q_rows);
+            case 2: return launch_bf16<2>(s, qkv, out, n_images, tokens, heads, q_rows);
+            case 3: return launch_bf16<3>(s, qkv, out, n_images, tokens, heads, q_rows);
+            case 4: return launch_bf16<4>(s, qkv, out, n_images, tokens, heads, q_rows);
+            case 5: return launch_bf16<5>(s, qkv, out, n_images, tokens, heads, q_rows);
+            case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads, q_rows);
+            case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads, q_rows);
             default: {
                 const int qblocks = ((tokens + 31) / 32 + ATT_WAVES - 1) / ATT_WAVES;
                 hipLaunchKernelGGL(attention_bf16_chunked_kernel, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s, qkv,
@@ -828,7 +852,7 @@ extern "C" int vithip_attention_bf16io(vithip_stream_t stream, const unsigned sh
             }
         }
     }
-    return attention_dispatch<bf16_t>(s, qkv, out, n_images, tokens, heads);
+    return attention_dispatch<bf16_t>(s, qkv, out, n_images, tokens, heads, q_rows);
 }
 
 // Tuning/test hook: 0 = keep the fp32-MFMA kernel for bf16 I/O, 1 (default) = bf16 MFMA attention.

@@ -100,12 +100,21 @@ unsigned long long vit_config_macs_per_image(const vit_config *cfg) {
     return (T - 1) * PK * D + cfg->depth * layer + D * cfg->num_classes;
 }
 
+unsigned long long vit_config_macs_per_image_pruned(const vit_config *cfg) {
+    const unsigned long long T = (unsigned long long)vit_config_tokens(cfg), D = cfg->embed_dim, H = cfg->hidden_dim,
+                             hd = D / cfg->num_heads;
+    /* last layer: Q projection, both attention products, out_proj, fc1, fc2 for one row instead of T */
+    const unsigned long long saved = (T - 1) * (D * D + 2 * cfg->num_heads * T * hd + D * D + 2 * D * H);
+    return vit_config_macs_per_image(cfg) - saved;
+}
+
 void vit_engine_default_options(vit_engine_options *opt) {
     opt->device = 0;
     opt->max_batch = 256;
     opt->profile = 0;
     opt->lanes = 1;
     opt->dtype = VIT_DTYPE_F32;
+    opt->prune_last_layer = 0;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -405,6 +414,9 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
      * allocations, half used); the residual stream x, LayerNorm statistics, softmax and every accumulation
      * stay fp32; patch embedding and the classifier head run the fp32 kernels. */
     unsigned short *y16 = (unsigned short *)e->y, *qkv16 = (unsigned short *)e->qkv, *h16 = (unsigned short *)e->hbuf;
+    /* prune_last_layer: see vit_engine_options.  The class rows of a [n*T][D] buffer are rows 0, T, 2T, ... = a matrix
+     * with leading dimension T*D, which every op here takes as it is. */
+    const int prune = e->opt.prune_last_layer && T <= 224;
     for (int l = 0; l < c->depth && bf16; ++l) {
         float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
         unsigned short **lw16 = e->w16 + 4 + VIT_WEIGHTS_PER_LAYER * l;
@@ -413,6 +425,36 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
             HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)D, y16 + ROWS(j) * D, (size_t)D,
                                                     lw[0], lw[1], lane[j].n * T, D));
             HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        if (prune && l == c->depth - 1) {
+            LANES { /* K and V of every token (in_proj rows D..3D), Q of the class rows only */
+                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_QKV, y16 + ROWS(j) * D, D, lw16[2] + (size_t)D * D, lw[3] + D, NULL,
+                                 qkv16 + ROWS(j) * 3 * D + D, 3 * D, lane[j].n * T, 2 * D, D, VITHIP_BF16_EPI_BF16))) return rc;
+                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_QKV, y16 + ROWS(j) * D, T * D, lw16[2], lw[3], NULL,
+                                 qkv16 + ROWS(j) * 3 * D, T * 3 * D, lane[j].n, D, D, VITHIP_BF16_EPI_BF16))) return rc;
+            }
+            LANES {
+                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
+                HIP_TRY(e, vithip_attention_bf16io_rows(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T,
+                                                        c->num_heads, 1));
+                HIP_TRY(e, stage_end(e, lane[j].s));
+            }
+            LANES
+                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, T * D, lw16[4], lw[5], e->x + ROWS(j) * D,
+                                 e->x + ROWS(j) * D, T * D, lane[j].n, D, D, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
+            LANES { /* LN2 of the class rows -> compact [n][D] at the head of the lane's y region */
+                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+                HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)T * D, y16 + ROWS(j) * D, (size_t)D,
+                                                        lw[6], lw[7], lane[j].n, D));
+                HIP_TRY(e, stage_end(e, lane[j].s));
+            }
+            LANES
+                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC1, y16 + ROWS(j) * D, D, lw16[8], lw[9], NULL,
+                                 h16 + ROWS(j) * H, H, lane[j].n, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
+            LANES
+                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
+                                 e->x + ROWS(j) * D, T * D, lane[j].n, D, H, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
+            break;
         }
         LANES
             if ((rc = gemm16(e, lane[j].s, VIT_STAGE_QKV, y16 + ROWS(j) * D, D, lw16[2], lw[3], NULL,
@@ -445,6 +487,36 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
             HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D,
                                             lw[0], lw[1], lane[j].n * T, D));
             HIP_TRY(e, stage_end(e, lane[j].s));
+        }
+        if (prune && l == c->depth - 1) { /* same sequence as the bf16 branch above, fp32 operators */
+            LANES {
+                if ((rc = gemm(e, lane[j].s, VIT_STAGE_QKV, e->y + ROWS(j) * D, D, lw[2] + (size_t)D * D, lw[3] + D, NULL,
+                               e->qkv + ROWS(j) * 3 * D + D, 3 * D, lane[j].n * T, 2 * D, D, VITHIP_EPI_BIAS))) return rc;
+                if ((rc = gemm(e, lane[j].s, VIT_STAGE_QKV, e->y + ROWS(j) * D, T * D, lw[2], lw[3], NULL,
+                               e->qkv + ROWS(j) * 3 * D, T * 3 * D, lane[j].n, D, D, VITHIP_EPI_BIAS))) return rc;
+            }
+            LANES {
+                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
+                HIP_TRY(e, vithip_attention_f32_rows(lane[j].s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, lane[j].n, T,
+                                                     c->num_heads, 1));
+                HIP_TRY(e, stage_end(e, lane[j].s));
+            }
+            LANES
+                if ((rc = gemm(e, lane[j].s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, T * D, lw[4], lw[5], e->x + ROWS(j) * D,
+                               e->x + ROWS(j) * D, T * D, lane[j].n, D, D, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
+            LANES {
+                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+                HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)T * D, e->y + ROWS(j) * D, (size_t)D,
+                                                lw[6], lw[7], lane[j].n, D));
+                HIP_TRY(e, stage_end(e, lane[j].s));
+            }
+            LANES
+                if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC1, e->y + ROWS(j) * D, D, lw[8], lw[9], NULL,
+                               e->hbuf + ROWS(j) * H, H, lane[j].n, H, D, VITHIP_EPI_BIAS_GELU))) return rc;
+            LANES
+                if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D,
+                               e->x + ROWS(j) * D, T * D, lane[j].n, D, H, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
+            break;
         }
         LANES /* QKV in_proj (ViT_seq.c:134-147) */
             if ((rc = gemm(e, lane[j].s, VIT_STAGE_QKV, e->y + ROWS(j) * D, D, lw[2], lw[3], NULL,
