@@ -148,6 +148,10 @@ def test_model_constants():
     cc = B.CConfig.of(synth.VIT_B16)
     assert L.vit_config_macs_per_image(C.byref(cc)) == 17_563_828_224 == synth.VIT_B16.macs_per_image
     assert synth.VIT_L16_384.macs_per_image == 191_066_300_416
+    # prune_last_layer: Q projection, out_proj, fc1, fc2 and both attention products of 196 of the 197 rows of ONE layer
+    T, D, H, heads, hd = 197, 768, 3072, 12, 64
+    saved = (T - 1) * (D * D + 2 * heads * T * hd + D * D + 2 * D * H)
+    assert L.vit_config_macs_per_image_pruned(C.byref(cc)) == 17_563_828_224 - saved
     sizes = [L.vit_config_weight_size(C.byref(cc), i) for i in range(152)]
     assert sum(sizes) == 86_567_656                       # torchvision vit_b_16 parameter count
     assert sizes == [int(np.prod(s)) for s in synth.VIT_B16.weight_shapes()]

@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         L.vit_config_weight_size.argtypes = [C.POINTER(CConfig), C.c_int]
         L.vit_config_macs_per_image.restype = C.c_ulonglong
         L.vit_config_macs_per_image.argtypes = [C.POINTER(CConfig)]
+        L.vit_config_macs_per_image_pruned.restype = C.c_ulonglong
+        L.vit_config_macs_per_image_pruned.argtypes = [C.POINTER(CConfig)]
         L.vit_config_b16.restype = CConfig
         L.load_image_data.restype = C.POINTER(CImageData)
         L.load_image_data.argtypes = [C.c_char_p]
