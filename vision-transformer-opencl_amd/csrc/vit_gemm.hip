@@ -373,13 +373,21 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue) {
         case 7: return launch_tile<256, 128, 128, 64, AMODE, 32, true>(stream, p, epilogue);
         case 8: return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
         case 10: return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);  // pipelined
-        default:
-            // auto: the persistent walk wins where the epilogue is light on registers (bias, bias+GELU:
-            // fc1 22.0 vs 23.0 ms per step); the residual epilogue needs 255 VGPRs there and is faster
-            // one tile per workgroup (fc2 21.7 vs 22.5 ms)
-            if (epilogue == VITHIP_EPI_BIAS_RESIDUAL)
+        default: {
+            // auto.  Large problems: the persistent walk wins where the epilogue is light on registers (bias, bias+GELU:
+            // fc1 22.0 vs 23.0 ms per step); the residual epilogue needs 255 VGPRs there and is faster one tile per
+            // workgroup (fc2 21.7 vs 22.5 ms).  Small problems (few rounds of 128x128 tiles over the 512 workgroup
+            // slots) are tile-quantisation-bound: 128x64 tiles double the workgroups.  Measured per stage at batch
+            // 32 / 64 / 128 (bench.py --batch B --gemm-tile 0|8): a single image 5.47 -> 3.64 ms, batch 64 +7 %; the
+            // thresholds leave every GEMM of the batch-256 metric (>= 1182 tiles per lane) on the large-problem kernels.
+            const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+            if (epilogue == VITHIP_EPI_BIAS_RESIDUAL) {
+                if (tiles < 1024) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
                 return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
+            }
+            if (tiles < 2048) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
             return vitgemm::launch_persistent(stream, p, epilogue, g_gemm_group);
+        }
     }
 }
 
