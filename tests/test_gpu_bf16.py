@@ -23,12 +23,16 @@ def test_f32_to_bf16_matches_round_to_nearest_even():
     assert np.array_equal(B.f32_to_bf16_device(x), B.to_bf16_bits(x))
 
 
-@pytest.fixture(params=[1, 2], ids=["two-stage", "ping-pong"])
+@pytest.fixture(params=[(1, True), (2, True), (2, False)], ids=["two-stage", "ping-pong", "ping-pong-two-barriers"])
 def variant(request):
-    """Both bf16 GEMM kernels behind vithip_gemm_bf16 (0 = auto picks ping-pong whenever K >= 128)."""
-    B.gemm_bf16_set_variant(request.param)
-    yield request.param
+    """Both bf16 GEMM kernels behind vithip_gemm_bf16 (0 = auto picks ping-pong whenever K >= 128), the ping-pong one
+    with both of its barrier schedules."""
+    v, one_barrier = request.param
+    B.gemm_bf16_set_variant(v)
+    B.gemm_bf16_set_sync(one_barrier)
+    yield v
     B.gemm_bf16_set_variant(0)
+    B.gemm_bf16_set_sync(True)
 
 
 def test_gemm_bf16_identity_asymmetric_exact(variant):

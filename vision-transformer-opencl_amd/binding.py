@@ -267,6 +267,11 @@ def gemm_bf16_set_variant(variant: int) -> None:
     hip_check(lib().vithip_gemm_bf16_set_variant(int(variant)), "vithip_gemm_bf16_set_variant")
 
 
+def gemm_bf16_set_sync(one_barrier: bool) -> None:
+    """Barrier schedule of the ping-pong kernel: True (default) one barrier per phase and wave, False two."""
+    hip_check(lib().vithip_gemm_bf16_set_sync(1 if one_barrier else 0), "vithip_gemm_bf16_set_sync")
+
+
 def layernorm_bf16out(x, gamma, beta) -> np.ndarray:
     """vithip_layernorm_f32_bf16out -> bf16 bits."""
     x = _as_f32(x)
