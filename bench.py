@@ -104,6 +104,11 @@ def main() -> None:
                     help="NOT the metric configuration: vit_engine_options.prune_last_layer (the last encoder layer computes "
                          "only the class rows; bit-identical probabilities, 7 %% less arithmetic).  FLOP figures then count "
                          "the executed work")
+    ap.add_argument("--no-stage-brackets", action="store_true",
+                    help="with --lanes 1: keep the per-launch event brackets out of the timed steps (they cost ~0.5 ms per "
+                         "forward at batch 1); the roofline pass then runs afterwards, as with lanes > 1")
+    ap.add_argument("--graph", action="store_true",
+                    help="vit_engine_options.use_graph: replay the forward as one hipGraph (needs --lanes 1; small batches)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
     args = ap.parse_args()
 
@@ -136,8 +141,8 @@ def main() -> None:
     weights = synth.make_weights(cfg, 1234)
     # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
     # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
-    eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1), lanes=args.lanes,
-                         dtype=args.dtype, prune_last_layer=args.prune_last_layer)
+    eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1 and not args.graph and not args.no_stage_brackets), lanes=args.lanes,
+                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph)
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the
@@ -186,7 +191,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_steps = args.steps
-    if args.lanes == 1:
+    if args.lanes == 1 and not args.graph and not args.no_stage_brackets:
         times = eng.stage_times()
     else:
         # kernel-level pass: same batch, same kernels, one lane, every launch bracketed by events on its stream
@@ -241,7 +246,7 @@ def main() -> None:
         "whole_model_tflops": round(model_tflops, 2),
         "whole_model_frac": round(model_tflops / peak, 4),
         "stage_ms_per_step": {s: round(r["ms"] / kernel_steps, 3) for s, r in times["stages"].items()},
-        "measured": ("HIP events around every launch during the timed steps" if args.lanes == 1 else
+        "measured": ("HIP events around every launch during the timed steps" if (args.lanes == 1 and not args.graph and not args.no_stage_brackets) else
                      f"HIP events around every launch in {kernel_steps} extra steps with lanes=1 after the timed region "
                      f"(the timed steps run {args.lanes} concurrent lanes, whose kernels overlap)"),
     }

@@ -43,6 +43,10 @@ typedef struct {
                            * the probabilities are bit-identical, 7 % of the reference's arithmetic is not executed
                            * (vit_config_macs_per_image_pruned).  Off by default: bench.py's metric counts the
                            * reference's full work.  tokens <= 224. */
+    int use_graph;   /* 1: vit_engine_forward_device() captures its launch sequence into a hipGraph the first time it sees
+                      * an (n, pointers, stream-kind) combination and replays the graph afterwards (default 0).  For
+                      * small batches the ~150 launches of a forward are a visible share of the latency.  Ignored
+                      * while profiling, with lanes > 1 and on the NULL stream (not capturable). */
 } vit_engine_options;
 
 enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };

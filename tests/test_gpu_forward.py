@@ -229,3 +229,33 @@ def test_attention_rows_only_touches_the_requested_rows():
     for b in range(n):
         assert np.array_equal(got[b * T], full[b * T])
         assert (got[b * T + 1:(b + 1) * T] == 7.0).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graph_replay_matches_direct_launches(dtype):
+    """vit_engine_options.use_graph: the first device-path forward captures the launch sequence into a hipGraph and
+    runs it, later forwards with the same arguments replay it; all of them must equal the directly launched forward."""
+    cfg = synth.VIT_SMALL
+    W = synth.make_weights(cfg, 21)
+    n = 5
+    a, b = synth.make_images(cfg, n, 3), synth.make_images(cfg, n, 4)
+    ref = {}
+    for use_graph in (False, True):
+        eng = B.Engine(cfg, max_batch=4, dtype=dtype, use_graph=use_graph)   # max_batch 4: two chunks inside one graph
+        eng.load_weights(W)
+        d_img = B.DeviceArray.from_numpy(a)
+        d_probs = B.DeviceArray((n, cfg.num_classes))
+        d_lab, d_p = B.DeviceArray((n,), np.int32), B.DeviceArray((n,))
+        outs = []
+        for images in (a, b, a):          # capture + run, replay on new data, replay again
+            B.hip_check(B.lib().vithip_memcpy_h2d(d_img.ptr, np.ascontiguousarray(images).ctypes.data, images.nbytes, None), "h2d")
+            B.hip_check(B.lib().vithip_device_sync(), "sync")
+            eng.forward_device(d_img.ptr, n, d_probs.ptr, d_lab.ptr, d_p.ptr)
+            eng.sync()
+            outs.append((d_probs.numpy().copy(), d_lab.numpy().copy()))
+        eng.close()
+        ref[use_graph] = outs
+    for (p0, l0), (p1, l1) in zip(ref[False], ref[True]):
+        assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
+    assert not np.array_equal(ref[True][0][0], ref[True][1][0])   # the replay really saw the new images
+    assert np.array_equal(ref[True][0][0], ref[True][2][0])

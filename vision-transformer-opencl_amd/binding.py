@@ -47,7 +47,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
-                ("dtype", C.c_int), ("prune_last_layer", C.c_int)]
+                ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -381,12 +381,12 @@ class Engine:
     """vit_engine (include/vit_engine.h): weights resident in HBM, batched forward."""
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
-                 lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False):
+                 lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
         opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
-                       1 if prune_last_layer else 0)
+                       1 if prune_last_layer else 0, 1 if use_graph else 0)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

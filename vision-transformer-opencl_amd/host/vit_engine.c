@@ -38,6 +38,9 @@ struct vit_engine {
     float *wblob;                /* all weights, one allocation */
     float **w;                   /* device pointer per weight index */
     unsigned short *wblob16;     /* bf16 copies of the GEMM weights (dtype bf16 only) */
+    /* use_graph: the captured forward and what it was captured for */
+    vithip_graph_t graph;
+    const float *g_images; float *g_probs; int *g_label; float *g_prob; int g_n;
     unsigned short **w16;        /* per weight index; NULL for tensors that stay fp32 */
     int weights_loaded;
 
@@ -115,6 +118,7 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->lanes = 1;
     opt->dtype = VIT_DTYPE_F32;
     opt->prune_last_layer = 0;
+    opt->use_graph = 0;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -215,6 +219,7 @@ void vit_engine_destroy(vit_engine *e) {
     if (e->stream) vithip_stream_sync(e->stream);
     if (e->ev_ready)
         for (int i = 0; i < 2 * MAX_EVENTS; ++i) vithip_event_destroy(e->ev[i]);
+    if (e->graph) vithip_graph_destroy(e->graph);
     vithip_free(e->x); vithip_free(e->y); vithip_free(e->qkv); vithip_free(e->hbuf);
     vithip_free(e->z); vithip_free(e->logits);
     if (e->copy_stream) { vithip_stream_sync(e->copy_stream); vithip_stream_destroy(e->copy_stream); }
@@ -579,6 +584,16 @@ int vit_engine_forward_device(vit_engine *e, const float *d_images, int n, float
     vithip_stream_t s = stream ? (vithip_stream_t)stream : e->stream;
     const size_t img = (size_t)e->cfg.in_chans * e->cfg.img_size * e->cfg.img_size;
     const size_t NC = (size_t)e->cfg.num_classes;
+    const int graphable = e->opt.use_graph && !e->opt.profile && e->opt.lanes == 1 && s != NULL;
+    if (graphable && e->graph && e->g_n == n && e->g_images == d_images && e->g_probs == d_probs &&
+        e->g_label == d_top1_label && e->g_prob == d_top1_prob) {
+        HIP_TRY(e, vithip_graph_launch(e->graph, s));
+        return VIT_OK;
+    }
+    if (graphable) {
+        if (e->graph) { vithip_graph_destroy(e->graph); e->graph = NULL; }
+        HIP_TRY(e, vithip_graph_begin(s));
+    }
     for (int done = 0; done < n; done += e->opt.max_batch) {
         const int nb = n - done < e->opt.max_batch ? n - done : e->opt.max_batch;
         int rc = forward_chunk(e, s, d_images + (size_t)done * img, nb, d_probs + (size_t)done * NC,
@@ -588,6 +603,11 @@ int vit_engine_forward_device(vit_engine *e, const float *d_images, int n, float
         if (e->opt.profile) e->pending_images += nb;
         /* read the brackets back lazily (it needs an event sync): only when the pool runs low */
         if (e->opt.profile && e->ev_used > MAX_EVENTS - 256 && (rc = collect_profile(e))) return rc;
+    }
+    if (graphable) { /* nothing ran yet: the launches above were recorded; instantiate and run them */
+        HIP_TRY(e, vithip_graph_end(s, &e->graph));
+        e->g_n = n; e->g_images = d_images; e->g_probs = d_probs; e->g_label = d_top1_label; e->g_prob = d_top1_prob;
+        HIP_TRY(e, vithip_graph_launch(e->graph, s));
     }
     return VIT_OK;
 }
