@@ -618,6 +618,28 @@ int vit_engine_sync(vit_engine *e) {
     return VIT_OK;
 }
 
+/* Host-pointer surface helpers.  The reference's ImageData keeps every image in its own malloc (Network.c:66-93), so a
+ * piece has to be gathered into pinned memory before it can be uploaded: one memcpy thread manages ~10 GB/s, which made
+ * the gather of the FIRST piece (nothing to overlap it with) 15 ms of a 512-image call.  The gather runs on a few OpenMP
+ * threads and a piece goes up in sub-pieces of 64 images, so the H2D copy of one sub-piece overlaps the gather of the
+ * next. */
+#define GATHER_THREADS 8
+#define SUB_PIECE 64
+static void gather_images(float *dst, const float *const *images, int first, int count, size_t img) {
+#pragma omp parallel for num_threads(GATHER_THREADS) schedule(static) if (count >= 8)
+    for (int i = 0; i < count; ++i) memcpy(dst + (size_t)i * img, images[first + i], img * sizeof(float));
+}
+static int stage_piece(vit_engine *e, int slot, const float *const *images, int first, int count, size_t img) {
+    for (int s0 = 0; s0 < count; s0 += SUB_PIECE) {
+        const int c = count - s0 < SUB_PIECE ? count - s0 : SUB_PIECE;
+        gather_images(e->pin_in[slot] + (size_t)s0 * img, images, first + s0, c, img);
+        HIP_TRY(e, vithip_memcpy_h2d(e->in_stage[slot] + (size_t)s0 * img, e->pin_in[slot] + (size_t)s0 * img,
+                                     (size_t)c * img * sizeof(float), e->copy_stream));
+    }
+    HIP_TRY(e, vithip_event_record(e->ev_h2d[slot], e->copy_stream));
+    return VIT_OK;
+}
+
 int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, float *const *probs) {
     if (!e) return VIT_ERR_ARG;
     if (!images || !probs || n <= 0) return fail(e, VIT_ERR_ARG, "forward_host: bad arguments (n=%d)", n);
@@ -638,9 +660,10 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
     const int np = (n + piece - 1) / piece;
 #define PIECE_N(i) ((i) == np - 1 ? n - (i) * piece : piece)
     /* stage piece 0 */
-    for (int i = 0; i < PIECE_N(0); ++i) memcpy(e->pin_in[0] + (size_t)i * img, images[i], img * sizeof(float));
-    HIP_TRY(e, vithip_memcpy_h2d(e->in_stage[0], e->pin_in[0], (size_t)PIECE_N(0) * img * sizeof(float), e->copy_stream));
-    HIP_TRY(e, vithip_event_record(e->ev_h2d[0], e->copy_stream));
+    {
+        int rc0 = stage_piece(e, 0, images, 0, PIECE_N(0), img);
+        if (rc0) return rc0;
+    }
     for (int k = 0; k < np; ++k) {
         const int b = k & 1, nb = PIECE_N(k);
         HIP_TRY(e, vithip_stream_wait_event(e->stream, e->ev_h2d[b]));
@@ -656,10 +679,8 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
                 memcpy(probs[first + i], e->pin_out[b ^ 1] + (size_t)i * NC, NC * sizeof(float));
         }
         if (k + 1 < np) { /* slot b^1 is free again (its H2D, compute and D2H are complete): refill it */
-            const int first = (k + 1) * piece, nn = PIECE_N(k + 1);
-            for (int i = 0; i < nn; ++i) memcpy(e->pin_in[b ^ 1] + (size_t)i * img, images[first + i], img * sizeof(float));
-            HIP_TRY(e, vithip_memcpy_h2d(e->in_stage[b ^ 1], e->pin_in[b ^ 1], (size_t)nn * img * sizeof(float), e->copy_stream));
-            HIP_TRY(e, vithip_event_record(e->ev_h2d[b ^ 1], e->copy_stream));
+            rc = stage_piece(e, b ^ 1, images, (k + 1) * piece, PIECE_N(k + 1), img);
+            if (rc) return rc;
         }
     }
     {
