@@ -19,7 +19,8 @@ stats() {  # name, bench args...
 }
 pmc() {  # name, counter, bench args...
     local name=$1 ctr=$2; shift 2
-    timeout -k 10 500 rocprofv3 --pmc "$ctr" --kernel-trace --output-format csv -d "$W/$name" -- \
+    # shellcheck disable=SC2086  ($ctr may hold several counter names)
+    timeout -k 10 500 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$W/$name" -- \
         python3 bench.py --no-cpu-baseline --lanes 1 --steps 2 --warmup 1 "$@" > /dev/null 2> "$W/$name.err"
     echo "pmc $name done"
 }
@@ -29,11 +30,15 @@ stats f32_default
 pmc f32_fetch FETCH_SIZE
 pmc f32_write WRITE_SIZE
 python3 tools/pmc_summary.py "$W/f32_fetch" "$W/f32_write" "$OUT/hbm_traffic_pmc_f32" 256
+pmc f32_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16"
+python3 tools/mfma_summary.py "$W/f32_mfma" "$OUT/mfma_util_f32.csv"
 if [ "$2" != "f32only" ]; then
     stats bf16_batch2048 --dtype bf16 --batch 2048 --steps 5 --warmup 2
     pmc bf16_fetch FETCH_SIZE --dtype bf16 --batch 2048
     pmc bf16_write WRITE_SIZE --dtype bf16 --batch 2048
     python3 tools/pmc_summary.py "$W/bf16_fetch" "$W/bf16_write" "$OUT/hbm_traffic_pmc_bf16" 2048
+    pmc bf16_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16" --dtype bf16 --batch 2048
+    python3 tools/mfma_summary.py "$W/bf16_mfma" "$OUT/mfma_util_bf16.csv"
     # BASELINE.json configs[4]: ViT-L/16-384, batch 1024, bf16 (no profiler)
     timeout -k 10 500 python3 bench.py --no-cpu-baseline --model l16_384 --dtype bf16 --batch 1024 --steps 3 --warmup 1 \
         > "$OUT/bench_bf16_l16_384_batch1024.json" 2> "$W/l16.err"
