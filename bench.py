@@ -70,6 +70,23 @@ def quiet_stdout(fn):
         os.close(devnull)
 
 
+def pmc_mfma(kernel, dtype, batch):
+    """(MFMA-busy %, clock GHz) of `kernel` from the committed rocprofv3 PMC pass (profiles/r01/mfma_util_<dtype>.csv,
+    tools/collect_profiles.sh); (None, None) when that pass does not cover this configuration."""
+    import csv
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import bench_key
+        with open(os.path.join(ROOT, "profiles", "r01", f"mfma_util_{dtype}.csv"), newline="") as f:
+            rows = [r for r in csv.DictReader(f) if bench_key(r["kernel"]) == kernel]
+    except (OSError, ImportError):
+        return None, None
+    if not rows or batch != (256 if dtype == "f32" else 2048):
+        return None, None
+    r = max(rows, key=lambda r: float(r["avg_us"]) * int(r["launches"]))
+    return float(r["mfma_busy_percent"]), float(r["clock_ghz_from_gui_active"])
+
+
 def stage_macs(cfg, batch):
     T, D, H = cfg.tokens, cfg.embed_dim, cfg.hidden_dim
     M = batch * T
@@ -240,6 +257,7 @@ def main() -> None:
     roofline = {
         "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom_name, args.dtype, B),
+        "mfma_busy_percent_rocprof": pmc_mfma(dom_name, args.dtype, B)[0], "clock_ghz_rocprof": pmc_mfma(dom_name, args.dtype, B)[1],
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
         "flop_per_launch": dom["flop"] / max(dom["launches"], 1),
         "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
