@@ -127,31 +127,44 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true",
                     help="vit_engine_options.use_graph: replay the forward as one hipGraph (needs --lanes 1; small batches)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the rank processes from this process even for --gpus 1 (N > 1 always does when not "
+                         "already launched): exercises the launcher and the RCCL gather at world size 1")
     args = ap.parse_args()
+
+    # ---- one process per GPU -------------------------------------------------------------------------
+    # `python bench.py --gpus N` started plainly: THIS process only spawns the N ranks (fresh interpreters, before
+    # anything here has imported torch or loaded the HIP library) and relays rank 0's JSON line.  Started by
+    # torch.distributed.run (WORLD_SIZE set) it is a rank already.  N = 1 without --spawn stays in-process, so
+    # `rocprofv3 -- python3 bench.py` profiles the process it launched.
+    pkg = importlib.import_module("vision-transformer-opencl_amd")
+    launch = pkg.launch
+    if not launch.launched() and (args.gpus > 1 or args.spawn):
+        rc, _ = launch.launch_ranks(os.path.abspath(__file__), [a for a in sys.argv[1:] if a != "--spawn"], args.gpus)
+        sys.exit(rc)
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    pkg = importlib.import_module("vision-transformer-opencl_amd")
     binding = importlib.import_module("vision-transformer-opencl_amd.binding")
     synth = pkg.synth
     cfg = pkg.VIT_B16 if args.model == "b16" else pkg.VIT_L16_384
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local_rank, world = launch.rank_env()
+    distributed = launch.launched()   # a launched rank takes the RCCL path even at world size 1
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if distributed:
+        launch.init_process_group("nccl", dev)
 
     B = args.batch
     binding.lib().vithip_gemm_set_tile(args.gemm_tile)
@@ -177,20 +190,20 @@ def main() -> None:
         images += 1e-3 * off.view(B, 1, 1, 1)
         probs = torch.empty((B, cfg.num_classes), device=dev, dtype=torch.float32)
         top1 = torch.empty((2, B), device=dev, dtype=torch.int32)  # row 0 labels, row 1 prob bits
-        gathered = torch.empty((world, 2, B), device=dev, dtype=torch.int32) if world > 1 else None
+        gathered = torch.empty((world, 2, B), device=dev, dtype=torch.int32) if distributed else None
     stream.synchronize()
     sptr = stream.cuda_stream
 
     def step():
         eng.forward_device(images.data_ptr(), B, probs.data_ptr(), top1[0].data_ptr(), top1[1].data_ptr(), sptr)
-        if world > 1:  # the one exchange of the path: everybody receives every image's (label, prob)
+        if distributed:  # the one exchange of the path: everybody receives every image's (label, prob)
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gathered.view(-1), top1.view(-1))
+                pkg.dp.gather_packed(top1, gathered)
 
     def fence():
         stream.synchronize()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -203,10 +216,13 @@ def main() -> None:
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    gather_ok = None
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the gathered records of this rank's slot must be this rank's own top-1 (checked outside the timed region)
+        gather_ok = bool(torch.equal(gathered[rank], top1))
     kernel_steps = args.steps
     if args.lanes == 1 and not args.graph and not args.no_stage_brackets:
         times = eng.stage_times()
@@ -328,12 +344,13 @@ def main() -> None:
                                     f"{'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} forward, batch {B} per GPU, synthetic weights and images "
                                     "(BASELINE.json configs[%d])" % (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2))),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
+                       "top1_gather": ("rccl all_gather, 8 B per image" + ("" if gather_ok else " (MISMATCH)")) if distributed else None,
                        "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }))
     eng.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

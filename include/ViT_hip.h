@@ -25,7 +25,10 @@
  * a NULL / mis-sized weight is reported by index instead of crashing; all image[0].n images
  * are processed as one batch.
  *
- * Environment: VIT_HIP_DEVICE (device ordinal, default 0), VIT_HIP_MAX_BATCH (chunk size,
+ * Environment: VIT_HIP_DEVICE (device ordinal, default 0); VIT_HIP_DEVICES ("all" or a comma list of ordinals, e.g.
+ * "0,1,2,3,4,5,6,7": one engine and one host thread per device, the weights uploaded once and replicated device to
+ * device, image[0..n) split into contiguous slices -- the reference's image loop, ViT_opencl.c:802, cut across the
+ * GPUs of the node; results are bit-identical to the single-device run); VIT_HIP_MAX_BATCH (chunk size per device,
  * default 256), VIT_HIP_LANES (concurrent sub-batches per chunk, default 2), VIT_HIP_DTYPE ("bf16" selects the bf16
  * matrix-pipe variant: same top-1, |dprob| <= 2e-2 against the fp32 reference instead of 1e-4; default fp32),
  * VIT_HIP_PRUNE_LAST_LAYER (1: vit_engine_options.prune_last_layer, bit-identical probabilities; default 0).
@@ -50,6 +53,17 @@ void Release_opencl(void);
 
 /* Drop the cached device copy of the weights (call after modifying `networks` in place). */
 void ViT_hip_invalidate_weights(void);
+/* Number of devices the facade drives (0 before initialize_hip). */
+int ViT_hip_device_count(void);
+/*
+ * Packed weight cache (vit_io.h, vit_weight_image): make the weights resident straight from a cache file -- one read,
+ * one host-to-device copy, one device-to-device copy per further device -- without load_weights() at all; afterwards
+ * ViT_hip() accepts any `networks` (NULL included).  source_dir (may be NULL) = the Network/ directory the file must
+ * still match.  Returns 0, or -1 when the file is absent, stale or for another model (then load_weights() as usual).
+ * ViT_hip_save_weight_cache writes the currently resident weights (0 / -1).
+ */
+int ViT_hip_load_weight_cache(const char *path, const char *source_dir);
+int ViT_hip_save_weight_cache(const char *path, const char *source_dir);
 
 #ifdef __cplusplus
 }

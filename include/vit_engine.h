@@ -14,6 +14,7 @@
 #ifndef VIT_ENGINE_H
 #define VIT_ENGINE_H
 
+#include "vit_io.h"
 #include "vit_types.h"
 
 #ifdef __cplusplus
@@ -85,6 +86,16 @@ const vit_config *vit_engine_config(const vit_engine *e);
  * The host arrays are only borrowed during the call.
  */
 int vit_engine_load_weights(vit_engine *e, const Network *weights, int count);
+/*
+ * The same from a device-layout weight image (vit_io.h: built once, or read from the cache file): ONE host-to-device
+ * copy of [fp32 tensors | bf16 GEMM operands]; an image without a bf16 section is converted on the device (one launch).
+ */
+int vit_engine_load_weight_image(vit_engine *e, const vit_weight_image *img);
+/* Replicate the resident weights of `src` into `dst` (same model and dtype, any two devices of the process) with one
+ * device-to-device copy -- over xGMI between GPUs, instead of another upload from the host. */
+int vit_engine_copy_weights(vit_engine *dst, vit_engine *src);
+/* Read the resident weights back as an image (bf16 section = the device's own conversion), e.g. to write the cache. */
+int vit_engine_read_weight_image(vit_engine *e, vit_weight_image *img);
 
 /*
  * Device-resident forward: d_images [n][C][S][S] fp32 -> d_probs [n][classes] fp32, both in

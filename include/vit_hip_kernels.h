@@ -56,6 +56,7 @@ int vithip_host_free(void *ptr);
 int vithip_memcpy_h2d(void *dst, const void *src, size_t bytes, vithip_stream_t stream);
 int vithip_memcpy_d2h(void *dst, const void *src, size_t bytes, vithip_stream_t stream);
 int vithip_memcpy_d2d(void *dst, const void *src, size_t bytes, vithip_stream_t stream);
+int vithip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, vithip_stream_t stream);
 int vithip_memset(void *dst, int value, size_t bytes, vithip_stream_t stream);
 int vithip_stream_create(vithip_stream_t *stream);
 int vithip_stream_destroy(vithip_stream_t stream);

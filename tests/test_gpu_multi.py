@@ -1,0 +1,151 @@
+"""Several engines in one process, weight replication, the packed weight cache on the device, the 2 GiB lane cap and the
+RCCL gather of bench.py -- everything that a 1-GPU box can say about the multi-device path (the N = 8 run itself is the
+driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from vit_amd import binding as B
+from vit_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def small():
+    cfg = synth.VIT_SMALL
+    return cfg, synth.make_weights(cfg, 7), synth.make_images(cfg, 11, 8)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_weight_replication_device_to_device(small, dtype):
+    cfg, W, imgs = small
+    a = B.Engine(cfg, max_batch=16, dtype=dtype)
+    a.load_weights(W)
+    b = B.Engine(cfg, max_batch=16, dtype=dtype)
+    with pytest.raises(B.VitError):
+        b.forward(imgs)                                  # no weights yet
+    b.copy_weights_from(a)
+    pa, pb = a.forward(imgs), b.forward(imgs)
+    assert np.array_equal(pa, pb)
+    c = B.Engine(cfg, max_batch=16, dtype="bf16" if dtype == "f32" else "f32")
+    with pytest.raises(B.VitError, match="dtype"):
+        c.copy_weights_from(a)
+    for e in (a, b, c):
+        e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_cache_loaded_engine_is_bit_identical_to_file_loaded_engine(small, dtype, tmp_path):
+    cfg, W, imgs = small
+    ref = B.Engine(cfg, max_batch=16, dtype=dtype)
+    ref.load_weights(W)                                  # Network[] path: packed on the host, bf16 converted on the device
+    want = ref.forward(imgs)
+    host_img = B.WeightImage.build(cfg, W, with_bf16=True)  # bf16 section converted on the HOST (what vit_main --cache writes)
+    path = str(tmp_path / "w.cache")
+    assert host_img.save(path) == 0
+    loaded = B.WeightImage.load(cfg, path)
+    eng = B.Engine(cfg, max_batch=16, dtype=dtype)
+    eng.load_weight_image(loaded)                        # one H2D, no conversion launch
+    assert np.array_equal(eng.forward(imgs), want)
+    dev_img = ref.read_weight_image()                    # the device's own bytes
+    assert np.array_equal(dev_img.f32_section(), host_img.f32_section())
+    if dtype == "bf16":
+        assert np.array_equal(dev_img.bf16_section(), host_img.bf16_section())   # host RNE == v_cvt_pk_bf16_f32
+    nob = B.WeightImage.build(cfg, W, with_bf16=False)   # an image without the bf16 section: converted on upload
+    eng2 = B.Engine(cfg, max_batch=16, dtype=dtype)
+    eng2.load_weight_image(nob)
+    assert np.array_equal(eng2.forward(imgs), want)
+    other = B.WeightImage.build(synth.VIT_TINY, synth.make_weights(synth.VIT_TINY, 1))
+    with pytest.raises(B.VitError, match="another model"):
+        eng2.load_weight_image(other)
+    for e in (ref, eng, eng2):
+        e.close()
+
+
+def test_reloading_weights_invalidates_the_captured_graph(small):
+    cfg, W, imgs = small
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_out = torch.empty((imgs.shape[0], cfg.num_classes), device=dev)
+    eng = B.Engine(cfg, max_batch=16, use_graph=True)
+    eng.load_weights(W)
+    for _ in range(2):                                   # capture, then replay
+        eng.forward_device(d_img.data_ptr(), imgs.shape[0], d_out.data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    first = d_out.cpu().numpy().copy()
+    W2 = synth.make_weights(cfg, 8)
+    eng.load_weights(W2)                                 # frees / rewrites the weight blob the graph pointed into
+    eng.forward_device(d_img.data_ptr(), imgs.shape[0], d_out.data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    plain = B.Engine(cfg, max_batch=16)
+    plain.load_weights(W2)
+    want = plain.forward(imgs)
+    assert np.array_equal(d_out.cpu().numpy(), want) and not np.array_equal(first, want)
+    eng.close()
+    plain.close()
+
+
+def test_facade_with_two_engines_splits_the_image_loop():
+    """VIT_HIP_DEVICES: one engine + host thread per listed device, image[0..n) cut into contiguous slices.  A 1-GPU box
+    lists device 0 twice -- two engines, two threads, weights replicated device-to-device -- and must reproduce the
+    single-engine result bit for bit, for even and ragged splits and for n < number of engines."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "vit_b16_e2e.npz"))
+    cfg = synth.VIT_B16
+    W = synth.make_weights(cfg, int(g["weight_seed"]))
+    imgs = synth.make_images(cfg, 5, int(g["image_seed"]))
+    single = B.facade_forward(imgs, W)
+    assert B.lib().ViT_hip_device_count() == 0            # released
+    os.environ["VIT_HIP_DEVICES"] = "0,0"
+    try:
+        L = B.lib()
+        L.initialize_opencl()
+        assert L.ViT_hip_device_count() == 2
+        L.Release_opencl()
+        for n in (5, 4, 1):
+            got = B.facade_forward(imgs[:n], W)
+            assert np.array_equal(got, single[:n]), n
+    finally:
+        del os.environ["VIT_HIP_DEVICES"]
+    n_gold = min(5, int(g["n_images"]))
+    assert float(np.abs(single[:n_gold] - g["probs"][:n_gold]).max()) <= 1e-4
+
+
+def test_fp32_chunk_is_capped_below_2gib_per_launch():
+    """ViT-L/16-384 fp32: one image's MLP hidden rows are 9.45 MB, so 227 images fill the 2 GiB a buffer descriptor
+    addresses (max_batch 256 used to fail mid-layer with hipErrorInvalidValue).  The engine now cuts the chunk."""
+    cfg = synth.ModelConfig(img_size=384, embed_dim=1024, depth=1, num_heads=16, hidden_dim=4096)
+    W = synth.make_weights(cfg, 31)
+    n = 230
+    imgs = np.tile(synth.make_images(cfg, 2, 32), (n // 2, 1, 1, 1))
+    imgs += (np.arange(n, dtype=np.float32) * 1e-3).reshape(n, 1, 1, 1)
+    big = B.Engine(cfg, max_batch=256, lanes=1)
+    big.load_weights(W)
+    got = big.forward(imgs)
+    big.close()
+    small_eng = B.Engine(cfg, max_batch=32, lanes=1)
+    small_eng.load_weights(W)
+    want = small_eng.forward(imgs)
+    small_eng.close()
+    assert np.array_equal(got, want)
+
+
+def test_bench_rank_takes_the_rccl_path_at_world_size_one():
+    """bench.py --spawn: the parent launches its rank (before touching the GPU), the rank initialises nccl (= RCCL),
+    all-gathers the packed top-1 records through dp.gather_packed on the forward's stream, and prints the JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VIT_LAUNCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["top1_gather"] == "rccl all_gather, 8 B per image"
+    assert rec["value"] > 0

@@ -62,23 +62,97 @@ def test_weight_loader_layout_rounding_and_gaps(tmp_path):
         assert np.array_equal(got[i], synth.round6(w).ravel()), f"tensor {i}"
 
 
-def test_packed_weight_cache_roundtrip(tmp_path):
+def _tiny_blobs(tmp_path, seed=9):
     cfg = synth.VIT_TINY
-    raw = [synth.uniform(9, i, int(np.prod(s)), -0.3, 0.3).reshape(s) for i, s in enumerate(cfg.weight_shapes())]
+    raw = [synth.uniform(seed, i, int(np.prod(s)), -0.3, 0.3).reshape(s) for i, s in enumerate(cfg.weight_shapes())]
     synth.write_weight_files(str(tmp_path), raw)
-    os.remove(tmp_path / "Weight_9_t9.bin")                      # gaps must survive the cache
-    first = B.load_weight_dir_cached(str(tmp_path), cfg.n_weights)     # scans the files, writes the cache
-    assert (tmp_path / "vit_weights.cache").exists()
+    return cfg, raw
+
+
+def test_packed_weight_cache_roundtrip_and_staleness(tmp_path):
+    cfg, raw = _tiny_blobs(tmp_path)
+    cache = tmp_path / "vit_weights.cache"
+    first = B.load_weight_dir_cached(cfg, str(tmp_path))              # scans the files, writes the cache
+    assert cache.exists()
+    for i, a in enumerate(first):
+        assert np.array_equal(a, synth.round6(raw[i]).ravel())
+    # served from the cache: make the blobs unreadable-as-weights without touching name/size/mtime
+    keep = {}
     for f in glob.glob(str(tmp_path / "Weight_*.bin")):
-        os.remove(f)                                                # now only the cache can answer
-    second = B.load_weight_dir_cached(str(tmp_path), cfg.n_weights)
-    for i, (a, b) in enumerate(zip(first, second)):
-        assert (a is None) == (b is None) == (i == 9)
-        if a is not None:
-            assert np.array_equal(a, b) and np.array_equal(a, synth.round6(raw[i]).ravel())
-    (tmp_path / "vit_weights.cache").write_bytes(b"garbage")       # a corrupt cache is ignored, not trusted
-    third = B.load_weight_dir_cached(str(tmp_path), cfg.n_weights)
-    assert all(w is None for w in third)
+        st = os.stat(f)
+        keep[f] = (open(f, "rb").read(), st)
+        open(f, "r+b").write(b"\xff" * st.st_size)
+        os.utime(f, ns=(st.st_atime_ns, st.st_mtime_ns))
+    second = B.load_weight_dir_cached(cfg, str(tmp_path))
+    for a, b in zip(first, second):
+        assert np.array_equal(a, b)
+    for f, (data, st) in keep.items():
+        open(f, "r+b").write(data)
+        os.utime(f, ns=(st.st_atime_ns, st.st_mtime_ns))
+    # a replaced blob (new mtime) makes the cache stale: the directory wins and the cache is rewritten
+    new7 = synth.uniform(77, 7, raw[7].size, -0.3, 0.3).astype(np.float32)
+    name7 = glob.glob(str(tmp_path / "Weight_7_*.bin"))[0]
+    new7.tofile(name7)
+    os.utime(name7, ns=(1_700_000_000_000_000_000, 1_700_000_000_000_000_000))
+    third = B.load_weight_dir_cached(cfg, str(tmp_path))
+    assert np.array_equal(third[7], synth.round6(new7)) and not np.array_equal(third[7], first[7])
+    fourth = B.load_weight_dir_cached(cfg, str(tmp_path))             # ... and the rewritten cache is valid again
+    assert np.array_equal(fourth[7], third[7])
+    cache.write_bytes(b"garbage")                                     # a corrupt cache is ignored, not trusted
+    fifth = B.load_weight_dir_cached(cfg, str(tmp_path))
+    assert np.array_equal(fifth[7], third[7])
+
+
+def test_packed_weight_cache_is_not_written_from_an_incomplete_set(tmp_path):
+    cfg, raw = _tiny_blobs(tmp_path)
+    os.remove(glob.glob(str(tmp_path / "Weight_9_*.bin"))[0])         # the reference tree itself ships 116 of 152 blobs
+    got = B.load_weight_dir_cached(cfg, str(tmp_path))
+    assert got[9] is None and got[8] is not None
+    assert not (tmp_path / "vit_weights.cache").exists()              # holes are never pinned into a cache
+    synth.write_weight_files(str(tmp_path), raw)                      # the blob arrives later: picked up at once
+    got = B.load_weight_dir_cached(cfg, str(tmp_path))
+    assert got[9] is not None and (tmp_path / "vit_weights.cache").exists()
+    # a cache that predates an added blob of an index it does not know is stale as well
+    (tmp_path / "Weight_3_extra_copy.bin").write_bytes(raw[3].astype(np.float32).tobytes())
+    assert B.WeightImage.load(cfg, str(tmp_path / "vit_weights.cache"), str(tmp_path)) is None
+    assert B.WeightImage.load(cfg, str(tmp_path / "vit_weights.cache"), None) is not None   # no directory: format check only
+
+
+def test_weight_image_is_the_device_layout(tmp_path):
+    cfg = synth.VIT_SMALL
+    W = synth.make_weights(cfg, 3)
+    img = B.WeightImage.build(cfg, W, with_bf16=True)
+    c = img.c
+    gemm = [i for i in range(cfg.n_weights) if i == 1 or (4 <= i < 4 + 12 * cfg.depth and (i - 4) % 12 in (2, 4, 8, 10))]
+    offs = [c.off[i] for i in range(cfg.n_weights)]
+    assert all(o % 128 == 0 for o in offs)                            # 512-B fp32 slots = 256-B bf16 slots
+    assert sorted(offs[i] for i in gemm) == sorted(offs)[:len(gemm)]  # GEMM operands lead the blob ...
+    assert c.gemm_floats == max(offs[i] + -(-W[i].size // 128) * 128 for i in gemm) == c.bf16_elems
+    for i, t in enumerate(img.tensors()):
+        assert np.array_equal(t, W[i].ravel())
+    f32, b16 = img.f32_section(), img.bf16_section()
+    assert np.array_equal(b16, B.to_bf16_bits(f32[:c.gemm_floats]))   # ... and the bf16 section mirrors them, RNE
+    path = str(tmp_path / "w.cache")
+    assert img.save(path) == 0
+    back = B.WeightImage.load(cfg, path)
+    assert np.array_equal(back.f32_section(), f32) and np.array_equal(back.bf16_section(), b16)
+    assert B.WeightImage.load(synth.VIT_TINY, path) is None           # another model's cache is refused
+    with pytest.raises(B.VitError):
+        B.WeightImage.build(cfg, W[:-1] + [None])
+
+
+def test_chunked_image_reader_matches_whole_file_loader(tmp_path):
+    cfg = synth.VIT_TINY
+    imgs = synth.make_images(cfg, 7, 5)
+    path = str(tmp_path / "input-7.bin")
+    synth.write_image_file(path, imgs)
+    n, chunks = B.read_image_file_chunked(path, 3)
+    assert n == 7 and [f for f, _ in chunks] == [0, 3, 6] and [c.shape[0] for _, c in chunks] == [3, 3, 1]
+    assert np.array_equal(np.concatenate([c for _, c in chunks]), imgs)
+    assert B.read_image_file_chunked(str(tmp_path / "missing.bin"), 3) is None
+    (tmp_path / "short.bin").write_bytes(open(path, "rb").read()[:-8])
+    n, chunks = B.read_image_file_chunked(str(tmp_path / "short.bin"), 4)
+    assert [c.shape[0] for _, c in chunks] == [4]                     # the torn last chunk is refused, not returned short
 
 
 def test_image_loader_roundtrip_and_failures(tmp_path):

@@ -403,6 +403,19 @@ class Engine:
         arr, keep = networks_from(weights)
         self._check(lib().vit_engine_load_weights(self._h, arr, len(weights)), "vit_engine_load_weights")
 
+    def load_weight_image(self, img: "WeightImage") -> None:
+        self._check(lib().vit_engine_load_weight_image(self._h, C.byref(img.c)), "vit_engine_load_weight_image")
+
+    def read_weight_image(self) -> "WeightImage":
+        img = WeightImage()
+        self._check(lib().vit_engine_read_weight_image(self._h, C.byref(img.c)), "vit_engine_read_weight_image")
+        return img
+
+    def copy_weights_from(self, other: "Engine") -> None:
+        L = lib()
+        L.vit_engine_copy_weights.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(L.vit_engine_copy_weights(self._h, other._h), "vit_engine_copy_weights")
+
     def forward(self, images: np.ndarray) -> np.ndarray:
         """Host path (the ViT_opencl-shaped one): per-image pointers in, per-image rows out."""
         images = _as_f32(images)
@@ -506,16 +519,104 @@ def load_weight_dir(directory: str, count: int):
     return out
 
 
-def load_weight_dir_cached(directory: str, count: int):
-    """load_weights_cached(): single-file cache next to the Weight_*.bin files."""
+def load_weight_dir_cached(cfg: ModelConfig, directory: str, cache_path: Optional[str] = None):
+    """load_weights_cached(): Network[] through the packed cache file (validated against the directory's files)."""
     L = lib()
-    L.load_weights_cached.argtypes = [C.c_char_p, C.POINTER(CNetwork), C.c_int]
+    L.load_weights_cached.argtypes = [C.POINTER(CConfig), C.c_char_p, C.POINTER(CNetwork), C.c_int, C.c_char_p]
+    count = cfg.n_weights
     nets = (CNetwork * count)()
-    L.load_weights_cached(directory.encode(), nets, count)
+    cc = CConfig.of(cfg)
+    L.load_weights_cached(C.byref(cc), directory.encode(), nets, count, cache_path.encode() if cache_path else None)
     out = [np.ctypeslib.as_array(nets[i].data, shape=(nets[i].size,)).copy() if nets[i].data else None
            for i in range(count)]
     L.free_weights(nets, count)
     return out
+
+
+class CWeightImage(C.Structure):  # include/vit_io.h: vit_weight_image
+    _fields_ = [("cfg", CConfig), ("count", C.c_int), ("f32_floats", C.c_size_t), ("gemm_floats", C.c_size_t),
+                ("bf16_elems", C.c_size_t), ("off", C.POINTER(C.c_size_t)), ("size", C.POINTER(C.c_size_t)),
+                ("f32", f32p), ("bf16", C.POINTER(C.c_ushort))]
+
+
+class WeightImage:
+    """vit_weight_image: the device layout of a model's weights on the host / in the cache file."""
+
+    def __init__(self):
+        self.c = CWeightImage()
+        L = lib()
+        L.vit_weight_image_build.argtypes = [C.POINTER(CWeightImage), C.POINTER(CConfig), C.POINTER(CNetwork), C.c_int, C.c_int]
+        L.vit_weight_image_free.argtypes = [C.POINTER(CWeightImage)]
+        L.vit_weight_image_save.argtypes = [C.POINTER(CWeightImage), C.c_char_p, C.c_char_p]
+        L.vit_weight_image_load.argtypes = [C.POINTER(CWeightImage), C.c_char_p, C.POINTER(CConfig), C.c_char_p]
+        L.vit_engine_load_weight_image.argtypes = [C.c_void_p, C.POINTER(CWeightImage)]
+        L.vit_engine_read_weight_image.argtypes = [C.c_void_p, C.POINTER(CWeightImage)]
+
+    @classmethod
+    def build(cls, cfg: ModelConfig, weights: Sequence[np.ndarray], with_bf16: bool = True) -> "WeightImage":
+        img = cls()
+        arr, keep = networks_from(weights)
+        cc = CConfig.of(cfg)
+        if lib().vit_weight_image_build(C.byref(img.c), C.byref(cc), arr, len(weights), 1 if with_bf16 else 0) != 0:
+            raise VitError("vit_weight_image_build: incomplete or mis-sized weight set")
+        return img
+
+    @classmethod
+    def load(cls, cfg: ModelConfig, path: str, source_dir: Optional[str] = None) -> Optional["WeightImage"]:
+        img = cls()
+        cc = CConfig.of(cfg)
+        rc = lib().vit_weight_image_load(C.byref(img.c), path.encode(), C.byref(cc), source_dir.encode() if source_dir else None)
+        return img if rc == 0 else None
+
+    def save(self, path: str, source_dir: Optional[str] = None) -> int:
+        return lib().vit_weight_image_save(C.byref(self.c), path.encode(), source_dir.encode() if source_dir else None)
+
+    def tensors(self):
+        return [np.ctypeslib.as_array(self.c.f32, shape=(self.c.f32_floats,))[self.c.off[i]:self.c.off[i] + self.c.size[i]].copy()
+                for i in range(self.c.count)]
+
+    def f32_section(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self.c.f32, shape=(self.c.f32_floats,)).copy()
+
+    def bf16_section(self) -> Optional[np.ndarray]:
+        if not self.c.bf16_elems:
+            return None
+        return np.ctypeslib.as_array(self.c.bf16, shape=(self.c.bf16_elems,)).copy()
+
+    def free(self) -> None:
+        lib().vit_weight_image_free(C.byref(self.c))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def read_image_file_chunked(path: str, chunk: int):
+    """vit_image_reader_*: list of (first_index, array) chunks, or None when the file cannot be opened."""
+    L = lib()
+    L.vit_image_reader_open.restype = C.c_void_p
+    L.vit_image_reader_open.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4
+    L.vit_image_reader_next.restype = C.POINTER(CImageData)
+    L.vit_image_reader_next.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.vit_image_reader_close.argtypes = [C.c_void_p]
+    dims = [C.c_int() for _ in range(4)]
+    r = L.vit_image_reader_open(path.encode(), *[C.byref(d) for d in dims])
+    if not r:
+        return None
+    out = []
+    while True:
+        first = C.c_int()
+        p = L.vit_image_reader_next(r, chunk, C.byref(first))
+        if not p:
+            break
+        k, c, h, w = p[0].n, p[0].c, p[0].h, p[0].w
+        assert all(p[i].n == k for i in range(k))
+        out.append((first.value, np.stack([np.ctypeslib.as_array(p[i].data, shape=(c, h, w)).copy() for i in range(k)])))
+        L.free_image_data(p)
+    L.vit_image_reader_close(r)
+    return dims[0].value, out
 
 
 def round_weights(w: np.ndarray) -> np.ndarray:

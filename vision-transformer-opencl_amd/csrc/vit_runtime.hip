@@ -52,6 +52,11 @@ int vithip_memcpy_d2h(void *dst, const void *src, size_t bytes, vithip_stream_t 
 int vithip_memcpy_d2d(void *dst, const void *src, size_t bytes, vithip_stream_t stream) {
     RET(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
 }
+int vithip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, vithip_stream_t stream) {
+    if (dst_device == src_device)
+        RET(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    RET(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, static_cast<hipStream_t>(stream)));
+}
 int vithip_memset(void *dst, int value, size_t bytes, vithip_stream_t stream) {
     RET(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
 }

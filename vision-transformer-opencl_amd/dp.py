@@ -34,6 +34,22 @@ def unpack_top1(packed):
     return packed[..., 0, :].contiguous(), packed[..., 1, :].contiguous().view(torch.float32)
 
 
+def gather_packed(packed, out=None, group=None):
+    """All-gather one packed [2][n] int32 record tensor per rank into out [world][2][n] (allocated when None).
+
+    This is the ONE exchange of the data-parallel path (north star: "RCCL over xGMI only to gather top-1"):
+    8 bytes per image, issued on the current stream of the tensor's device, so it is ordered after the forward
+    that produced `packed` when both use the same stream.  nccl (= RCCL) for GPU tensors, gloo for CPU tensors.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world,) + tuple(packed.shape), dtype=torch.int32, device=packed.device)
+    dist.all_gather_into_tensor(out.view(-1), packed.contiguous().view(-1), group=group)
+    return out
+
+
 def gather_top1(labels, probs, counts=None, group=None):
     """All-gather the per-image top-1 records of every rank, in rank (= image) order.
 
@@ -50,8 +66,7 @@ def gather_top1(labels, probs, counts=None, group=None):
     width = max(counts)
     if n_local < width:
         packed = torch.nn.functional.pad(packed, (0, width - n_local))
-    out = torch.empty((world, 2, width), dtype=torch.int32, device=packed.device)
-    dist.all_gather_into_tensor(out.view(-1), packed.contiguous().view(-1), group=group)
+    out = gather_packed(packed, None, group)
     lab, pr = [], []
     for r in range(world):
         l, p = unpack_top1(out[r])

@@ -15,12 +15,14 @@
  */
 #include "vit_engine.h"
 
+#include <limits.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "vit_hip_kernels.h"
+#include "vit_io.h"
 
 #define VIT_MAX_LANES 4
 #define MAX_EVENTS 4096   /* stage brackets kept in flight before they are read back */
@@ -35,9 +37,11 @@ struct vit_engine {
     vithip_stream_t stream;      /* engine-owned in-order stream */
     vithip_stream_t aux_stream[VIT_MAX_LANES - 1]; /* extra lanes of a chunk (forward_chunk) */
     vithip_event_t ev_fork, ev_join[VIT_MAX_LANES - 1];
-    float *wblob;                /* all weights, one allocation */
+    float *wblob;                /* all weights, ONE allocation: [fp32 section | bf16 GEMM operands] (vit_weight_image) */
+    size_t wblob_bytes;          /* bytes of it that carry data (the allocation has a read-only tail pad behind) */
     float **w;                   /* device pointer per weight index */
-    unsigned short *wblob16;     /* bf16 copies of the GEMM weights (dtype bf16 only) */
+    unsigned short *wblob16;     /* the bf16 section inside wblob (dtype bf16 only) */
+    int lane_cap;                /* most images one lane may hold (32-bit buffer offsets of the fp32 kernels) */
     /* use_graph: the captured forward and what it was captured for */
     vithip_graph_t graph;
     const float *g_images; float *g_probs; int *g_label; float *g_prob; int g_n;
@@ -171,6 +175,19 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
     if (rc) return rc;
     e->tokens = vit_config_tokens(&e->cfg);
     e->n_weights = VIT_WEIGHT_COUNT(e->cfg.depth);
+    {
+        /* The fp32 GEMMs (and the patch gather) address an A operand through a buffer descriptor with 32-bit byte
+         * offsets (csrc/vit_gemm.hip): one launch may span < 2 GiB of images, LN output, attention output or MLP hidden
+         * rows.  That bounds the images of one LANE; larger chunks are cut down in forward_device/forward_host. */
+        const size_t T_ = (size_t)e->tokens, per[3] = {T_ * (size_t)e->cfg.hidden_dim, T_ * (size_t)e->cfg.embed_dim,
+                                                         (size_t)e->cfg.in_chans * e->cfg.img_size * e->cfg.img_size};
+        size_t worst = per[0] > per[1] ? per[0] : per[1];
+        if (per[2] > worst) worst = per[2];
+        const size_t cap = ((size_t)0x7fffffff - 4096) / (worst * sizeof(float));
+        if (cap < 1) return fail(e, VIT_ERR_ARG, "model too large: one image needs %zu bytes of fp32 rows, the fp32 kernels "
+                                                 "address < 2 GiB per launch", worst * sizeof(float));
+        e->lane_cap = cap > (size_t)INT_MAX ? INT_MAX : (int)cap;
+    }
 
     int ndev = 0;
     HIP_TRY(e, vithip_device_count(&ndev));
@@ -216,6 +233,7 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
 
 void vit_engine_destroy(vit_engine *e) {
     if (!e) return;
+    vithip_set_device(e->opt.device);
     if (e->stream) vithip_stream_sync(e->stream);
     if (e->ev_ready)
         for (int i = 0; i < 2 * MAX_EVENTS; ++i) vithip_event_destroy(e->ev[i]);
@@ -231,7 +249,6 @@ void vit_engine_destroy(vit_engine *e) {
         if (e->ev_done[b]) vithip_event_destroy(e->ev_done[b]);
     }
     vithip_free(e->wblob);
-    vithip_free(e->wblob16);
     free(e->w16);
     for (int j = 0; j < VIT_MAX_LANES - 1; ++j) {
         if (e->aux_stream[j]) { vithip_stream_sync(e->aux_stream[j]); vithip_stream_destroy(e->aux_stream[j]); }
@@ -261,51 +278,118 @@ int vit_engine_set_profile(vit_engine *e, int on) {
 
 /* ------------------------------------------------------------------------------------------ */
 
+/* A captured forward holds the old weight addresses in its kernel arguments: drop it with them. */
+static void drop_graph(vit_engine *e) {
+    if (e->graph) { vithip_graph_destroy(e->graph); e->graph = NULL; }
+    e->g_n = 0; e->g_images = NULL; e->g_probs = NULL; e->g_label = NULL; e->g_prob = NULL;
+}
+
+#define WEIGHT_TAIL_PAD (1u << 20) /* GEMM loaders read (never use) up to a tile of rows past the last tensor */
+
+/* (Re)allocate the device blob for this model and point w[] / w16[] into it (no data yet). */
+static int alloc_weight_blob(vit_engine *e, const size_t *off, size_t f32_floats, size_t gemm_floats) {
+    const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
+    const size_t bytes = f32_floats * sizeof(float) + (bf16 ? gemm_floats * sizeof(unsigned short) : 0);
+    HIP_TRY(e, vithip_set_device(e->opt.device));
+    if (e->stream) HIP_TRY(e, vithip_stream_sync(e->stream));
+    drop_graph(e);
+    e->weights_loaded = 0;
+    if (e->wblob && e->wblob_bytes != bytes) { vithip_free(e->wblob); e->wblob = NULL; }
+    if (!e->wblob) {
+        HIP_TRY(e, vithip_malloc((void **)&e->wblob, bytes + WEIGHT_TAIL_PAD));
+        HIP_TRY(e, vithip_memset((char *)e->wblob + bytes, 0, WEIGHT_TAIL_PAD, e->stream));
+    }
+    e->wblob_bytes = bytes;
+    e->wblob16 = bf16 ? (unsigned short *)(e->wblob + f32_floats) : NULL;
+    for (int i = 0; i < e->n_weights; ++i) {
+        e->w[i] = e->wblob + off[i];
+        e->w16[i] = (bf16 && off[i] < gemm_floats) ? e->wblob16 + off[i] : NULL;
+    }
+    return VIT_OK;
+}
+
+int vit_engine_load_weight_image(vit_engine *e, const vit_weight_image *img) {
+    if (!e || !img || !img->f32) return e ? fail(e, VIT_ERR_ARG, "null weight image") : VIT_ERR_ARG;
+    if (memcmp(&img->cfg, &e->cfg, sizeof(vit_config)) != 0 || img->count != e->n_weights)
+        return fail(e, VIT_ERR_WEIGHTS, "weight image was built for another model configuration");
+    int rc = alloc_weight_blob(e, img->off, img->f32_floats, img->gemm_floats);
+    if (rc) return rc;
+    const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
+    /* ONE host-to-device copy: the image is the device layout ([fp32 | bf16] adjacent on both sides) */
+    const size_t up = img->f32_floats * sizeof(float) + ((bf16 && img->bf16_elems) ? img->bf16_elems * sizeof(unsigned short) : 0);
+    HIP_TRY(e, vithip_memcpy_h2d(e->wblob, img->f32, up, e->stream));
+    if (bf16 && !img->bf16_elems) /* image without a bf16 section: convert the GEMM-operand region on the device, one launch */
+        HIP_TRY(e, vithip_f32_to_bf16(e->stream, e->wblob, e->wblob16, img->gemm_floats));
+    HIP_TRY(e, vithip_stream_sync(e->stream));
+    e->weights_loaded = 1;
+    return VIT_OK;
+}
+
 int vit_engine_load_weights(vit_engine *e, const Network *weights, int count) {
     if (!e || !weights) return e ? fail(e, VIT_ERR_ARG, "null weights") : VIT_ERR_ARG;
     if (count != e->n_weights)
         return fail(e, VIT_ERR_WEIGHTS, "expected %d weight tensors for depth %d, got %d", e->n_weights, e->cfg.depth, count);
-    size_t total = 0;
     for (int i = 0; i < count; ++i) {
         const size_t want = vit_config_weight_size(&e->cfg, i);
         if (!weights[i].data)
             return fail(e, VIT_ERR_WEIGHTS, "weight %d is missing (Network[%d].data == NULL; expected %zu floats)", i, i, want);
         if (weights[i].size != want)
             return fail(e, VIT_ERR_WEIGHTS, "weight %d has %zu floats, expected %zu", i, weights[i].size, want);
-        total += (want + 63) & ~(size_t)63; /* 256-byte aligned slots */
     }
-    HIP_TRY(e, vithip_set_device(e->opt.device));
-    if (e->wblob) { vithip_stream_sync(e->stream); vithip_free(e->wblob); e->wblob = NULL; }
-    HIP_TRY(e, vithip_malloc((void **)&e->wblob, total * sizeof(float)));
-    size_t off = 0;
-    for (int i = 0; i < count; ++i) {
-        e->w[i] = e->wblob + off;
-        HIP_TRY(e, vithip_memcpy_h2d(e->w[i], weights[i].data, weights[i].size * sizeof(float), e->stream));
-        off += (weights[i].size + 63) & ~(size_t)63;
-    }
-    if (e->opt.dtype == VIT_DTYPE_BF16) {
-        /* bf16 copies of the four GEMM weights of every layer (in_proj, out_proj, fc1, fc2), converted on
-         * the device from the rounded fp32 upload (round to nearest even); everything else stays fp32 */
-        static const int gemm_slots[4] = {2, 4, 8, 10};
-        size_t total16 = (weights[1].size + 63) & ~(size_t)63;   /* conv_proj weight: patch embedding on the bf16 pipe */
-        for (int l = 0; l < e->cfg.depth; ++l)
-            for (int k = 0; k < 4; ++k) total16 += (weights[4 + VIT_WEIGHTS_PER_LAYER * l + gemm_slots[k]].size + 63) & ~(size_t)63;
-        if (e->wblob16) { vithip_free(e->wblob16); e->wblob16 = NULL; }
-        HIP_TRY(e, vithip_malloc((void **)&e->wblob16, total16 * sizeof(unsigned short)));
-        size_t off16 = (weights[1].size + 63) & ~(size_t)63;
-        e->w16[1] = e->wblob16;
-        HIP_TRY(e, vithip_f32_to_bf16(e->stream, e->w[1], e->w16[1], weights[1].size));
-        for (int l = 0; l < e->cfg.depth; ++l)
-            for (int k = 0; k < 4; ++k) {
-                const int idx = 4 + VIT_WEIGHTS_PER_LAYER * l + gemm_slots[k];
-                e->w16[idx] = e->wblob16 + off16;
-                HIP_TRY(e, vithip_f32_to_bf16(e->stream, e->w[idx], e->w16[idx], weights[idx].size));
-                off16 += (weights[idx].size + 63) & ~(size_t)63;
-            }
-    }
-    HIP_TRY(e, vithip_stream_sync(e->stream));
-    e->weights_loaded = 1;
+    /* the separately malloc'd tensors of the reference's Network[] (Network.c:147-191) are packed into the device
+     * layout on the host (8 threads), then uploaded with one copy; bf16 operands are converted on the device */
+    vit_weight_image img;
+    if (vit_weight_image_build(&img, &e->cfg, weights, count, 0) != 0) return fail(e, VIT_ERR_NOMEM, "out of host memory packing the weights");
+    const int rc = vit_engine_load_weight_image(e, &img);
+    vit_weight_image_free(&img);
+    return rc;
+}
+
+int vit_engine_copy_weights(vit_engine *dst, vit_engine *src) {
+    if (!dst || !src) return VIT_ERR_ARG;
+    if (!src->weights_loaded) return fail(dst, VIT_ERR_STATE, "copy_weights: the source engine has no weights");
+    if (memcmp(&dst->cfg, &src->cfg, sizeof(vit_config)) != 0 || dst->opt.dtype != src->opt.dtype)
+        return fail(dst, VIT_ERR_ARG, "copy_weights: engines differ in model configuration or dtype");
+    size_t *off = (size_t *)malloc(sizeof(size_t) * (size_t)dst->n_weights);
+    if (!off) return fail(dst, VIT_ERR_NOMEM, "out of host memory");
+    size_t gemm_floats = 0;
+    const size_t f32_floats = vit_weight_layout(&dst->cfg, off, NULL, &gemm_floats);
+    int rc = alloc_weight_blob(dst, off, f32_floats, gemm_floats);
+    free(off);
+    if (rc) return rc;
+    /* device-to-device: on a multi-GPU node this crosses xGMI once per replica instead of PCIe (the in-process form of
+     * "upload to GPU 0 + broadcast") */
+    HIP_TRY(dst, vithip_memcpy_peer(dst->wblob, dst->opt.device, src->wblob, src->opt.device, dst->wblob_bytes, dst->stream));
+    HIP_TRY(dst, vithip_stream_sync(dst->stream));
+    dst->weights_loaded = 1;
     return VIT_OK;
+}
+
+int vit_engine_read_weight_image(vit_engine *e, vit_weight_image *img) {
+    if (!e || !img) return VIT_ERR_ARG;
+    if (!e->weights_loaded) return fail(e, VIT_ERR_STATE, "read_weight_image: no weights loaded");
+    /* an empty image of the right shape (built from a zero-filled model would be wasteful: allocate through the loader) */
+    Network *tmp = (Network *)calloc((size_t)e->n_weights, sizeof(Network));
+    if (!tmp) return fail(e, VIT_ERR_NOMEM, "out of host memory");
+    size_t *off = (size_t *)malloc(sizeof(size_t) * (size_t)e->n_weights), *size = (size_t *)malloc(sizeof(size_t) * (size_t)e->n_weights);
+    size_t gemm_floats = 0;
+    const size_t f32_floats = (off && size) ? vit_weight_layout(&e->cfg, off, size, &gemm_floats) : 0;
+    float *host = f32_floats ? (float *)malloc(e->wblob_bytes) : NULL;
+    int rc = host ? VIT_OK : fail(e, VIT_ERR_NOMEM, "out of host memory");
+    if (!rc) {
+        rc = vithip_set_device(e->opt.device) || vithip_memcpy_d2h(host, e->wblob, e->wblob_bytes, e->stream) ||
+             vithip_stream_sync(e->stream);
+        if (rc) rc = fail(e, VIT_ERR_HIP, "read_weight_image: device-to-host copy failed");
+    }
+    if (!rc) {
+        for (int i = 0; i < e->n_weights; ++i) { tmp[i].data = host + off[i]; tmp[i].size = size[i]; }
+        const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
+        if (vit_weight_image_build(img, &e->cfg, tmp, e->n_weights, bf16) != 0) rc = fail(e, VIT_ERR_NOMEM, "out of host memory");
+        /* the bf16 section is taken from the DEVICE (its own conversion), not re-derived on the host */
+        if (!rc && bf16) memcpy(img->bf16, host + f32_floats, gemm_floats * sizeof(unsigned short));
+    }
+    free(host); free(off); free(size); free(tmp);
+    return rc;
 }
 
 /* ---- stage launch helpers -------------------------------------------------------------------- */
@@ -576,6 +660,14 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
     return VIT_OK;
 }
 
+/* Images per forward_chunk call: the workspace holds max_batch, and no lane may exceed lane_cap (see vit_engine_create). */
+static int chunk_limit(const vit_engine *e) {
+    int lanes = e->opt.lanes < 1 ? 1 : (e->opt.lanes > VIT_MAX_LANES ? VIT_MAX_LANES : e->opt.lanes);
+    if (e->opt.dtype == VIT_DTYPE_BF16) return e->opt.max_batch; /* bf16 kernels rebase their descriptors per tile */
+    const long cap = (long)e->lane_cap * lanes;
+    return cap < e->opt.max_batch ? (int)cap : e->opt.max_batch;
+}
+
 int vit_engine_forward_device(vit_engine *e, const float *d_images, int n, float *d_probs,
                               int *d_top1_label, float *d_top1_prob, void *stream) {
     if (!e) return VIT_ERR_ARG;
@@ -584,6 +676,8 @@ int vit_engine_forward_device(vit_engine *e, const float *d_images, int n, float
     vithip_stream_t s = stream ? (vithip_stream_t)stream : e->stream;
     const size_t img = (size_t)e->cfg.in_chans * e->cfg.img_size * e->cfg.img_size;
     const size_t NC = (size_t)e->cfg.num_classes;
+    HIP_TRY(e, vithip_set_device(e->opt.device)); /* the current device is per host thread: several engines may share a process */
+    const int chunk = chunk_limit(e);
     const int graphable = e->opt.use_graph && !e->opt.profile && e->opt.lanes == 1 && s != NULL;
     if (graphable && e->graph && e->g_n == n && e->g_images == d_images && e->g_probs == d_probs &&
         e->g_label == d_top1_label && e->g_prob == d_top1_prob) {
@@ -594,12 +688,18 @@ int vit_engine_forward_device(vit_engine *e, const float *d_images, int n, float
         if (e->graph) { vithip_graph_destroy(e->graph); e->graph = NULL; }
         HIP_TRY(e, vithip_graph_begin(s));
     }
-    for (int done = 0; done < n; done += e->opt.max_batch) {
-        const int nb = n - done < e->opt.max_batch ? n - done : e->opt.max_batch;
+    for (int done = 0; done < n; done += chunk) {
+        const int nb = n - done < chunk ? n - done : chunk;
         int rc = forward_chunk(e, s, d_images + (size_t)done * img, nb, d_probs + (size_t)done * NC,
                                d_top1_label ? d_top1_label + done : NULL,
                                d_top1_prob ? d_top1_prob + done : NULL);
-        if (rc) return rc;
+        if (rc) {
+            if (graphable) { /* never leave the caller's stream in capture mode: end the capture, discard what it recorded */
+                vithip_graph_t g = NULL;
+                if (vithip_graph_end(s, &g) == 0 && g) vithip_graph_destroy(g);
+            }
+            return rc;
+        }
         if (e->opt.profile) e->pending_images += nb;
         /* read the brackets back lazily (it needs an event sync): only when the pool runs low */
         if (e->opt.profile && e->ev_used > MAX_EVENTS - 256 && (rc = collect_profile(e))) return rc;
@@ -655,8 +755,8 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
      * stream uploads them; the results of piece i-1 are scattered to the caller's rows meanwhile.
      * A single chunk of >= 64 images is cut in two so that even the reference-sized call overlaps.
      */
-    int piece = e->opt.max_batch;
-    if (n <= e->opt.max_batch && n >= 64) piece = (n + 1) / 2;
+    int piece = chunk_limit(e);
+    if (n <= piece && n >= 64) piece = (n + 1) / 2;
     const int np = (n + piece - 1) / piece;
 #define PIECE_N(i) ((i) == np - 1 ? n - (i) * piece : piece)
     /* stage piece 0 */

@@ -18,7 +18,13 @@
 
 /* ---- images -------------------------------------------------------------------------------- */
 
-ImageData *load_image_data(const char *filename) {
+struct vit_image_reader {
+    FILE *f;
+    int n, c, h, w;
+    int next; /* index of the first image not handed out yet */
+};
+
+vit_image_reader *vit_image_reader_open(const char *filename, int *n, int *c, int *h, int *w) {
     FILE *f = fopen(filename, "rb");
     if (!f) {
         perror("load_image_data: cannot open image file");
@@ -30,33 +36,63 @@ ImageData *load_image_data(const char *filename) {
         fclose(f);
         return NULL;
     }
-    const int n = hdr[0], c = hdr[1], h = hdr[2], w = hdr[3];
-    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || (double)c * h * w > 1e9) {
-        fprintf(stderr, "load_image_data: implausible header n=%d c=%d h=%d w=%d\n", n, c, h, w);
+    if (hdr[0] <= 0 || hdr[1] <= 0 || hdr[2] <= 0 || hdr[3] <= 0 || (double)hdr[1] * hdr[2] * hdr[3] > 1e9) {
+        fprintf(stderr, "load_image_data: implausible header n=%d c=%d h=%d w=%d\n", hdr[0], hdr[1], hdr[2], hdr[3]);
         fclose(f);
         return NULL;
     }
-    const size_t per = (size_t)c * h * w;
-    ImageData *images = (ImageData *)calloc((size_t)n, sizeof(ImageData));
-    if (!images) {
+    vit_image_reader *r = (vit_image_reader *)calloc(1, sizeof(*r));
+    if (!r) {
         perror("load_image_data: out of memory");
         fclose(f);
         return NULL;
     }
-    for (int i = 0; i < n; ++i) {
-        images[i].n = n; /* every element carries the total count (Network.c:77) */
-        images[i].c = c;
-        images[i].h = h;
-        images[i].w = w;
+    r->f = f; r->n = hdr[0]; r->c = hdr[1]; r->h = hdr[2]; r->w = hdr[3];
+    if (n) *n = r->n;
+    if (c) *c = r->c;
+    if (h) *h = r->h;
+    if (w) *w = r->w;
+    return r;
+}
+
+ImageData *vit_image_reader_next(vit_image_reader *r, int max_images, int *first) {
+    if (!r || max_images <= 0 || r->next >= r->n) return NULL;
+    const int k = r->n - r->next < max_images ? r->n - r->next : max_images;
+    const size_t per = (size_t)r->c * r->h * r->w;
+    ImageData *images = (ImageData *)calloc((size_t)k, sizeof(ImageData));
+    if (!images) {
+        perror("load_image_data: out of memory");
+        return NULL;
+    }
+    for (int i = 0; i < k; ++i) {
+        images[i].n = k; /* every element carries the count of its array (Network.c:77) */
+        images[i].c = r->c;
+        images[i].h = r->h;
+        images[i].w = r->w;
         images[i].data = (float *)malloc(per * sizeof(float));
-        if (!images[i].data || fread(images[i].data, sizeof(float), per, f) != per) {
+        if (!images[i].data || fread(images[i].data, sizeof(float), per, r->f) != per) {
             perror("load_image_data: short read or out of memory");
-            fclose(f);
             free_image_data(images);
             return NULL;
         }
     }
-    fclose(f);
+    if (first) *first = r->next;
+    r->next += k;
+    return images;
+}
+
+void vit_image_reader_close(vit_image_reader *r) {
+    if (!r) return;
+    fclose(r->f);
+    free(r);
+}
+
+ImageData *load_image_data(const char *filename) { /* the whole file as one array (Network.c:24-97) */
+    int n = 0;
+    vit_image_reader *r = vit_image_reader_open(filename, &n, NULL, NULL, NULL);
+    if (!r) return NULL;
+    ImageData *images = vit_image_reader_next(r, n, NULL);
+    vit_image_reader_close(r);
     return images;
 }
 
@@ -141,68 +177,6 @@ void free_weights(Network network[], int count) {
     }
 }
 
-/* ---- packed weight cache ------------------------------------------------------------------- */
-
-#define VITW_MAGIC 0x57544956u /* "VITW" little endian */
-#define VITW_VERSION 1u
-
-int vit_save_weight_cache(const char *path, const Network network[], int count) {
-    FILE *fp = fopen(path, "wb");
-    if (!fp) return -1;
-    uint32_t hdr[3] = {VITW_MAGIC, VITW_VERSION, (uint32_t)count};
-    int ok = fwrite(hdr, sizeof(uint32_t), 3, fp) == 3;
-    for (int i = 0; ok && i < count; ++i) {
-        const uint64_t n = network[i].data ? (uint64_t)network[i].size : 0;
-        ok = fwrite(&n, sizeof(n), 1, fp) == 1;
-    }
-    for (int i = 0; ok && i < count; ++i)
-        if (network[i].data && network[i].size) ok = fwrite(network[i].data, sizeof(float), network[i].size, fp) == network[i].size;
-    if (fclose(fp) != 0) ok = 0;
-    if (!ok) remove(path);
-    return ok ? 0 : -1;
-}
-
-int vit_load_weight_cache(const char *path, Network network[], int count) {
-    FILE *fp = fopen(path, "rb");
-    if (!fp) return -1;
-    uint32_t hdr[3];
-    if (fread(hdr, sizeof(uint32_t), 3, fp) != 3 || hdr[0] != VITW_MAGIC || hdr[1] != VITW_VERSION || hdr[2] != (uint32_t)count) {
-        fclose(fp);
-        return -1;
-    }
-    uint64_t *sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(count > 0 ? count : 1));
-    if (!sizes || fread(sizes, sizeof(uint64_t), (size_t)count, fp) != (size_t)count) {
-        free(sizes);
-        fclose(fp);
-        return -1;
-    }
-    for (int i = 0; i < count; ++i) { network[i].data = NULL; network[i].size = 0; }
-    int ok = 1;
-    for (int i = 0; ok && i < count; ++i) {
-        if (!sizes[i]) continue;
-        float *buf = (float *)malloc((size_t)sizes[i] * sizeof(float));
-        if (!buf || fread(buf, sizeof(float), (size_t)sizes[i], fp) != (size_t)sizes[i]) {
-            free(buf);
-            ok = 0;
-            break;
-        }
-        network[i].data = buf;
-        network[i].size = (size_t)sizes[i];
-    }
-    free(sizes);
-    fclose(fp);
-    if (!ok) free_weights(network, count);
-    return ok ? 0 : -1;
-}
-
-void load_weights_cached(const char *directory, Network network[], int count) {
-    char path[1024];
-    snprintf(path, sizeof(path), "%s/vit_weights.cache", directory);
-    if (vit_load_weight_cache(path, network, count) == 0) return;
-    load_weights(directory, network, count);
-    (void)vit_save_weight_cache(path, network, count); /* best effort: a read-only directory just stays uncached */
-}
-
 /* ---- results ------------------------------------------------------------------------------- */
 
 int vit_argmax(const float *probs, int classes) {
@@ -212,15 +186,20 @@ int vit_argmax(const float *probs, int classes) {
     return best;
 }
 
-int vit_write_results(FILE *fp, float *const *probs, int n, int classes, int fix_argmax) {
-    int pred = 0; /* Main.c:62 declares it once, outside the image loop */
+int vit_write_results_from(FILE *fp, float *const *probs, int n, int classes, int fix_argmax, int first_index, int *pred_io) {
+    int pred = pred_io ? *pred_io : 0; /* Main.c:62 declares it once, outside the image loop */
     for (int i = 0; i < n; ++i) {
         if (fix_argmax) pred = 0;
         for (int j = 1; j < classes; ++j)
             if (probs[i][j] > probs[i][pred]) pred = j;
-        if (fprintf(fp, "[%d] label: %d / prob: %.6f\n", i, pred, probs[i][pred]) < 0) return -1;
+        if (fprintf(fp, "[%d] label: %d / prob: %.6f\n", first_index + i, pred, probs[i][pred]) < 0) return -1;
     }
+    if (pred_io) *pred_io = pred;
     return 0;
+}
+
+int vit_write_results(FILE *fp, float *const *probs, int n, int classes, int fix_argmax) {
+    return vit_write_results_from(fp, probs, n, classes, fix_argmax, 0, NULL);
 }
 
 int vit_write_results_file(const char *path, float *const *probs, int n, int classes, int fix_argmax) {
