@@ -70,25 +70,23 @@ def test_cache_loaded_engine_is_bit_identical_to_file_loaded_engine(small, dtype
 
 def test_reloading_weights_invalidates_the_captured_graph(small):
     cfg, W, imgs = small
-    import torch
-    dev = torch.device("cuda", 0)
-    stream = torch.cuda.Stream(device=dev)
-    d_img = torch.from_numpy(imgs).to(dev)
-    d_out = torch.empty((imgs.shape[0], cfg.num_classes), device=dev)
+    n = imgs.shape[0]
+    d_img = B.DeviceArray.from_numpy(imgs)
+    d_out = B.DeviceArray((n, cfg.num_classes))
     eng = B.Engine(cfg, max_batch=16, use_graph=True)
     eng.load_weights(W)
     for _ in range(2):                                   # capture, then replay
-        eng.forward_device(d_img.data_ptr(), imgs.shape[0], d_out.data_ptr(), stream=stream.cuda_stream)
-    stream.synchronize()
-    first = d_out.cpu().numpy().copy()
+        eng.forward_device(d_img.ptr, n, d_out.ptr)
+    eng.sync()
+    first = d_out.numpy().copy()
     W2 = synth.make_weights(cfg, 8)
     eng.load_weights(W2)                                 # frees / rewrites the weight blob the graph pointed into
-    eng.forward_device(d_img.data_ptr(), imgs.shape[0], d_out.data_ptr(), stream=stream.cuda_stream)
-    stream.synchronize()
+    eng.forward_device(d_img.ptr, n, d_out.ptr)
+    eng.sync()
     plain = B.Engine(cfg, max_batch=16)
     plain.load_weights(W2)
     want = plain.forward(imgs)
-    assert np.array_equal(d_out.cpu().numpy(), want) and not np.array_equal(first, want)
+    assert np.array_equal(d_out.numpy(), want) and not np.array_equal(first, want)
     eng.close()
     plain.close()
 
