@@ -1,0 +1,92 @@
+"""HIP operators on the reference's REAL tensors against vectors the reference's own functions produced
+(tests/golden/real_weights_b16.npz; generator oracle/gen_golden_real.py).  Real ViT-B/16 weights are not the tame
+U(+-0.035) of the synthetic model: out_proj |w| reaches 0.50, ln_2.weight has std 0.19-0.26, and the inputs carry
+"massive" residual channels (x30) -- exactly what the 1e-4 bar and the bf16 variant had not met before.
+
+fp32 bar: |d| <= 2e-5 x the tensor's magnitude (fp32 accumulation order; same as the synthetic-weight op tests).
+bf16: the kernel must equal "operands rounded to bf16, exact products, fp32 accumulation" to accumulation accuracy, and
+its distance to the fp32 reference vector -- the inherent bf16 operand rounding -- is asserted against 2e-2 x magnitude.
+End-to-end real-weight parity is unpinned (36 weight blobs and input-100.bin are absent upstream).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from test_real_weights import GOLD, D, T, activation_inputs, head_input
+from vit_amd import binding as B
+from vit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLD)
+
+
+def mag(a):
+    return float(np.abs(a).max())
+
+
+def bf16(x):
+    return B.from_bf16_bits(B.to_bf16_bits(x))
+
+
+def test_patch_embed_and_ln1_on_real_conv_proj(g):
+    cfg = synth.VIT_B16
+    seed, rows = int(g["seed"]), list(g["rows"])
+    image = synth.make_images(cfg, 1, seed)
+    x = B.patch_embed(cfg, image, g["w1"], g["w2"], g["w0"], g["w3"])[0]
+    assert np.abs(x[rows] - g["embed_rows"]).max() <= 2e-5 * mag(g["embed_rows"])
+    assert abs(float(x.astype(np.float64).sum()) - float(g["embed_sum"])) <= 1e-5 * np.abs(x).sum()
+    y = B.layernorm(x, g["w4"], g["w5"])
+    assert np.abs(y[rows] - g["ln1_rows"]).max() <= 2e-5 * mag(g["ln1_rows"])
+    # bf16 pipe: conv_proj weight and pixels rounded to bf16, fp32 accumulate, fp32 bias/pos/cls
+    xb = B.patch_embed_bf16(cfg, image, g["w1"], g["w2"], g["w0"], g["w3"])[0]
+    err = float(np.abs(xb[rows] - g["embed_rows"]).max())
+    print("bf16 patch embed on real conv_proj: max |d| =", err, "of", mag(g["embed_rows"]))
+    assert err <= 2e-2 * mag(g["embed_rows"])
+    assert np.array_equal(xb[0], x[0])                             # class row: cls + pos, no matrix product involved
+    yb = B.from_bf16_bits(B.layernorm_bf16out(x, g["w4"], g["w5"]))
+    assert np.abs(yb[rows] - g["ln1_rows"]).max() <= 2.0 ** -8 * mag(g["ln1_rows"]) + 2e-5
+
+
+def test_out_proj_residual_and_ln2_on_real_weights(g):
+    seed, rows = int(g["seed"]), list(g["rows"])
+    for l in g["outproj_layers"]:
+        a, xres = activation_inputs(seed, int(l))
+        ow, ob = g[f"outproj_w_{l}"], g[f"outproj_b_{l}"]
+        want_r, want_z = g[f"resid_rows_{l}"], g[f"ln2_rows_{l}"]
+        r = B.gemm(a, ow, ob, residual=xres, epilogue=B.EPI_BIAS_RESIDUAL)
+        assert np.abs(r[rows] - want_r).max() <= 2e-5 * mag(want_r), int(l)
+        assert abs(float(r.astype(np.float64).sum()) - float(g[f"resid_sum_{l}"])) <= 1e-5 * np.abs(r).sum()
+        z = B.layernorm(r, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"])
+        assert np.abs(z[rows] - want_z).max() <= 2e-5 * mag(want_z) + 1e-6, int(l)
+        # bf16 matrix pipe, fp32 residual stream
+        a16, w16 = B.to_bf16_bits(a), B.to_bf16_bits(ow)
+        rb = B.gemm_bf16(a16, w16, ob, residual=xres, epilogue=B.BF16_EPI_F32_RESIDUAL)
+        exact = (B.from_bf16_bits(a16)[rows].astype(np.float64) @ B.from_bf16_bits(w16).astype(np.float64).T
+                 + ob.astype(np.float64) + xres[rows].astype(np.float64))
+        assert np.abs(rb[rows] - exact).max() <= 2e-5 * mag(want_r), int(l)       # the kernel's own arithmetic
+        lin_mag = mag(want_r - xres[rows])                                         # magnitude of the projection itself
+        err = float(np.abs(rb[rows] - want_r).max())
+        print(f"layer {int(l)}: bf16 out_proj vs fp32 reference: max |d| = {err:.4f}, projection magnitude {lin_mag:.2f}")
+        assert err <= 2e-2 * lin_mag, int(l)
+        zb = B.from_bf16_bits(B.layernorm_bf16out(r, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"]))
+        assert np.abs(zb[rows] - want_z).max() <= 2.0 ** -8 * mag(want_z) + 2e-5, int(l)
+
+
+def test_final_ln_and_head_on_real_weights(g):
+    seed = int(g["seed"])
+    xf = head_input(seed)[:8]
+    z = B.layernorm(xf, g["ln_w"], g["ln_b"])
+    assert np.abs(z - g["final_ln"]).max() <= 2e-5 * mag(g["final_ln"])
+    logits = B.gemm(z, g["head_w"], g["head_b"])
+    assert np.abs(logits - g["head_logits"]).max() <= 2e-5 * mag(g["head_logits"])
+    assert (logits.argmax(1) == g["head_logits"].argmax(1)).all()
+    # the class-row LayerNorm of the engine reads rows with a stride of tokens*dim: same operator, strided
+    p, lab, pr = B.softmax_top1(logits)
+    ref = np.exp(g["head_logits"].astype(np.float64) - g["head_logits"].max(1, keepdims=True))
+    ref /= ref.sum(1, keepdims=True)
+    assert np.abs(p - ref).max() <= 1e-4 and (lab == ref.argmax(1)).all()
