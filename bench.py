@@ -40,19 +40,24 @@ STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it
 }
 
 
+PROFILE_ROUND = "r02"   # profiles/<round>/: the committed rocprofv3 passes the replayed counter fields come from
+
+
 def pmc_traffic(kernel, dtype, batch):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01/README.md: separate
+    """(HBM bytes per launch of `kernel`, provenance) from the committed PMC passes (profiles/<round>/README.md: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, summarised by tools/pmc_summary.py).
-    Not collected live: counters need the profiler.  None when the passes do not cover this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01", f"hbm_traffic_pmc_{dtype}.json")
+    NOT collected live -- counters need the profiler -- so the value is a replay and says so (roofline.replayed_from).
+    (None, None) when the passes do not cover this configuration."""
+    rel = os.path.join("profiles", PROFILE_ROUND, f"hbm_traffic_pmc_{dtype}.json")
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, rel)) as f:
             rec = json.load(f)
     except OSError:
-        return None
-    if rec.get("batch") != batch:
-        return None
-    return rec["kernels"].get(kernel)
+        return None, None
+    if rec.get("batch") != batch or kernel not in rec.get("kernels", {}):
+        return None, None
+    return rec["kernels"][kernel], {"path": rel, "device": rec.get("device"), "commit": rec.get("commit"),
+                                    "collected": rec.get("collected")}
 
 
 def quiet_stdout(fn):
@@ -77,7 +82,7 @@ def pmc_mfma(kernel, dtype, batch):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         from pmc_summary import bench_key
-        with open(os.path.join(ROOT, "profiles", "r01", f"mfma_util_{dtype}.csv"), newline="") as f:
+        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, f"mfma_util_{dtype}.csv"), newline="") as f:
             rows = [r for r in csv.DictReader(f) if bench_key(r["kernel"]) == kernel]
     except (OSError, ImportError):
         return None, None
@@ -167,12 +172,11 @@ def main() -> None:
         launch.init_process_group("nccl", dev)
 
     B = args.batch
-    binding.lib().vithip_gemm_set_tile(args.gemm_tile)
     weights = synth.make_weights(cfg, 1234)
     # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
     # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
     eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1 and not args.graph and not args.no_stage_brackets), lanes=args.lanes,
-                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph)
+                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph, gemm_tile=args.gemm_tile)
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the
@@ -270,10 +274,21 @@ def main() -> None:
     achieved = dom["flop"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     gemm_ms = sum(v["ms"] for k, v in per_kernel.items() if k.startswith("gemm"))
     gemm_flop = sum(v["flop"] for k, v in per_kernel.items() if k.startswith("gemm"))
+    traffic, traffic_src = pmc_traffic(dom_name, args.dtype, B)
+    busy, clock = pmc_mfma(dom_name, args.dtype, B)
+    replayed = None
+    if traffic_src or busy is not None:
+        # counter-derived fields cannot be read without the profiler: they are REPLAYED from the committed rocprofv3
+        # passes of this same command (another run, possibly another device of the pool) -- everything else in this
+        # object is measured live in this process
+        replayed = dict(traffic_src or {"path": os.path.join("profiles", PROFILE_ROUND, f"mfma_util_{args.dtype}.csv")},
+                        fields=[k for k, v in (("traffic", traffic), ("mfma_busy_percent_rocprof", busy),
+                                               ("clock_ghz_rocprof", clock)) if v is not None],
+                        live=False)
     roofline = {
         "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
-        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom_name, args.dtype, B),
-        "mfma_busy_percent_rocprof": pmc_mfma(dom_name, args.dtype, B)[0], "clock_ghz_rocprof": pmc_mfma(dom_name, args.dtype, B)[1],
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+        "mfma_busy_percent_rocprof": busy, "clock_ghz_rocprof": clock, "replayed_from": replayed,
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
         "flop_per_launch": dom["flop"] / max(dom["launches"], 1),
         "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,

@@ -48,6 +48,7 @@ typedef struct {
                       * an (n, pointers, stream-kind) combination and replays the graph afterwards (default 0).  For
                       * small batches the ~150 launches of a forward are a visible share of the latency.  Ignored
                       * while profiling, with lanes > 1 and on the NULL stream (not capturable). */
+    int gemm_tile;   /* tuning: vithip_gemm_args.tile for every fp32 GEMM of this engine (0 = auto, the default) */
 } vit_engine_options;
 
 enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };

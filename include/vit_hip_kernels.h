@@ -94,17 +94,15 @@ typedef struct {
     float *C; int ldc;
     int M, N, K;
     int epilogue;
+    /* tuning, per call (the library keeps no process-wide tuning state); 0 = auto:
+     * tile: 0 = auto (128x128 tile, K step 32: persistent walk for the bias and bias+GELU epilogues, one pipelined tile
+     *   per workgroup for bias+residual; 128x64 tiles for small problems); classic loop: 1 = 128x128, 2 = 256x128,
+     *   3 = 128x64, 4 = 128x128 K16, 5 = 128x64 K16; pipelined loop: 10 = 128x128, 6 = 128x128 K16, 7 = 256x128,
+     *   8 = 128x64; 9 = persistent 128x128.
+     * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default 8; 1 = plain N-fastest order). */
+    int tile, group_m;
 } vithip_gemm_args;
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
-/* Tuning hook for benchmarks.  0 = auto (128x128 tile, K step 32: persistent walk for the bias and
- * bias+GELU epilogues, one pipelined tile per workgroup for bias+residual);
- * classic loop: 1 = 128x128, 2 = 256x128, 3 = 128x64, 4 = 128x128 K16, 5 = 128x64 K16;
- * pipelined loop: 10 = 128x128, 6 = 128x128 K16, 7 = 256x128, 8 = 128x64;  9 = persistent 128x128;
- * 101-105 = timing-only probe builds of the classic 128x128 kernel (wrong results by construction). */
-int vithip_gemm_set_tile(int tile);
-/* Tuning hook: tile rows per L2 group of the tile walk (default 8; 1 = plain N-fastest order). */
-int vithip_gemm_set_group(int group_m);
-
 /* ---- bf16 variant (BASELINE.json configs[2]) ---------------------------------
  * bf16 values are raw uint16 (upper half of the fp32 bit pattern, round-to-nearest-even). */
 enum { VITHIP_BF16_EPI_BF16 = 0, VITHIP_BF16_EPI_BF16_GELU = 1, VITHIP_BF16_EPI_F32_RESIDUAL = 2,
@@ -117,38 +115,32 @@ typedef struct {
     void *C; int ldc;                   /* bf16 (EPI_BF16, EPI_BF16_GELU) or fp32 (EPI_F32_RESIDUAL) */
     int M, N, K;                        /* K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0 */
     int epilogue;
+    /* tuning/testing, per call; all 0 = default:
+     * variant: 0 auto (ping-pong kernel whenever K >= 128), 1 two-stage kernel (vit_gemm_bf16.hip), 2 ping-pong kernel
+     *   (vit_gemm_bf16_pp.hip; invalid-value error when K < 128);
+     * two_barriers: barrier schedule of the ping-pong kernel, 0 = one barrier per phase and wave (default), 1 = two;
+     * stagger: start-up skew between its persistent workgroups, units of 512 cycles per position in the XCD (0..64). */
+    int variant, two_barriers, stagger;
 } vithip_gemm_bf16_args;
 /* C = epilogue(A . W^T + bias) on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16 in the ping-pong kernel,
  * v_mfma_f32_32x32x16_bf16 in the two-stage one), fp32 accumulate.  BF16_GELU rounds gelu(acc + bias) to bf16 (a
  * polynomial erfc whose error stays below 5 % of half a bf16 ulp); F32_RESIDUAL adds an fp32 residual in fp32. */
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
-/* tuning/testing: 0 auto (default: ping-pong kernel whenever K >= 128), 1 two-stage kernel (vit_gemm_bf16.hip),
- * 2 ping-pong kernel (vit_gemm_bf16_pp.hip; invalid-value error when K < 128); 3, 4 = its instrumented probe builds */
-int vithip_gemm_bf16_set_variant(int variant);
-/* tuning: barrier schedule of the ping-pong kernel: 1 (default) = one barrier per phase and wave, 0 = two */
-int vithip_gemm_bf16_set_sync(int one_barrier);
-/* tuning: start-up skew between the persistent workgroups of the ping-pong kernel, units of 512 cycles per
- * position inside the XCD (0..64) */
-int vithip_gemm_bf16_set_stagger(int units);
-/* probe only: cap the number of persistent workgroups of the event-log build (variant 4) */
-int vithip_gemm_bf16_set_max_workgroups(int n);
-/* probe only: variant 3 = ping-pong kernel with s_memtime stamps (8 waves x 32 u64 of workgroup 0) written to buf */
-int vithip_gemm_bf16_set_debug_buffer(void *buf);
 /* LayerNorm with fp32 statistics and a bf16 store; attention reading bf16 Q/K/V [n*tokens][3*heads*64] and
- * writing bf16 [n*tokens][heads*64]: both products on bf16 MFMA with fp32 softmax (P rounded to bf16 once), or,
- * after vithip_attention_bf16_set_mfma(0), K/V widened to fp32 in LDS and the fp32 kernel's arithmetic. */
+ * writing bf16 [n*tokens][heads*64]: both products on bf16 MFMA with fp32 softmax (P rounded to bf16 once);
+ * vithip_attention_bf16io_f32math: same I/O, K/V widened to fp32 in LDS and the fp32 kernel's arithmetic (cross-check). */
 int vithip_layernorm_f32_bf16out(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *y, size_t ldy,
                                  const float *gamma, const float *beta, int rows, int dim);
 int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
                             int n_images, int tokens, int heads);
+int vithip_attention_bf16io_f32math(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
+                                    int n_images, int tokens, int heads);
 /* As vithip_attention_f32 / vithip_attention_bf16io, but only the first q_rows query rows of every image are computed
  * and stored (rows q_rows.. of `out` are left untouched); tokens <= 224.  q_rows = 1 is the class token. */
 int vithip_attention_f32_rows(vithip_stream_t stream, const float *qkv, float *out, int n_images, int tokens, int heads,
                               int q_rows);
 int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images,
                                  int tokens, int heads, int q_rows);
-/* 1 (default): bf16 MFMA products (resident kernel up to 224 tokens, chunked online-softmax kernel beyond); 0: fp32 MFMA. */
-int vithip_attention_bf16_set_mfma(int on);
 /* Patch embedding on the bf16 matrix pipe (same result layout as vithip_patch_embed_f32: x[n][tokens][D] fp32 with
  * class token and pos_emb applied; ViT_seq.c:25-101): the images are cut into bf16 patch rows
  * (patches16: workspace of n * (img/patch)^2 * chans*patch^2 bf16), multiplied with the bf16 conv weight
@@ -160,15 +152,6 @@ int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const u
                             int embed_dim);
 /* dst[i] = bf16(src[i]), round to nearest even; count % 4 == 0. */
 int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short *dst, size_t count);
-
-/* Measurement probe: register-only fp32 MFMA loop; each wave issues iters*32 v_mfma_f32_32x32x2_f32
- * (4096 flop each).  Used by tools/gemm_probe.py to read the sustained matrix clock. */
-int vithip_probe_mfma_f32(vithip_stream_t stream, float *out, int blocks, int threads, int iters);
-/* Waves 0-3 of every 512-thread block issue iters*32 MFMAs, waves 4-7 valu_iters*64 independent v_fma_f32. */
-/* Store-path probe (tools/store_probe.py): per wave `iters` 16-B-per-lane stores; mode 0 = 1 KB contiguous, 1 = 16 rows x
- * 64 B, 2 = 8 rows x 128 B at row stride `stride` bytes; cycles[2*wave] = issue span, [2*wave+1] = until complete. */
-int vithip_probe_store(vithip_stream_t stream, void *out, int blocks, int threads, int iters, int mode, size_t stride, void *cycles);
-int vithip_probe_mfma_vs_valu(vithip_stream_t stream, float *out, int blocks, int iters, int valu_iters);
 
 /*
  * Patch embedding straight from NCHW images (implicit GEMM over the 16x16 patches), with the
@@ -199,8 +182,6 @@ int vithip_layernorm_f32(vithip_stream_t stream, const float *x, size_t ldx, flo
  */
 int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
                          int n_images, int tokens, int heads);
-/* Probe hook (tools/attn_probe.py): 8 x u64 cycle stamps per (image, head) workgroup; NULL disables. */
-int vithip_attention_set_debug_buffer(void *buf);
 
 /*
  * probs[r][0..classes) = softmax(logits[r]) (ViT_seq.c:304-324) and the top-1 record

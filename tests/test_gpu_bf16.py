@@ -24,15 +24,14 @@ def test_f32_to_bf16_matches_round_to_nearest_even():
 
 
 @pytest.fixture(params=[(1, True), (2, True), (2, False)], ids=["two-stage", "ping-pong", "ping-pong-two-barriers"])
-def variant(request):
+def variant(request, monkeypatch):
     """Both bf16 GEMM kernels behind vithip_gemm_bf16 (0 = auto picks ping-pong whenever K >= 128), the ping-pong one
-    with both of its barrier schedules."""
+    with both of its barrier schedules -- selected per call (vithip_gemm_bf16_args.variant / .two_barriers): the
+    library has no process-wide tuning state."""
     v, one_barrier = request.param
-    B.gemm_bf16_set_variant(v)
-    B.gemm_bf16_set_sync(one_barrier)
+    plain = B.gemm_bf16
+    monkeypatch.setattr(B, "gemm_bf16", lambda *a, **k: plain(*a, variant=v, two_barriers=not one_barrier, **k))
     yield v
-    B.gemm_bf16_set_variant(0)
-    B.gemm_bf16_set_sync(True)
 
 
 def test_gemm_bf16_identity_asymmetric_exact(variant):
@@ -121,11 +120,7 @@ def test_attention_bf16_io(oracle, n, T, heads, mfma):
     D = heads * 64
     bits = B.to_bf16_bits(u(13, (n * T, 3 * D), 1.5))
     qkv = B.from_bf16_bits(bits)                                               # the exact values the kernel sees
-    B.lib().vithip_attention_bf16_set_mfma(mfma)
-    try:
-        got = B.from_bf16_bits(B.attention_bf16io(bits, n, T, heads)).reshape(n, T, D)
-    finally:
-        B.lib().vithip_attention_bf16_set_mfma(1)
+    got = B.from_bf16_bits(B.attention_bf16io(bits, n, T, heads, f32math=not mfma)).reshape(n, T, D)
     # fp32 inside + one bf16 rounding of the output; with bf16 P add sum_j |dp_j v_j| <~ 2^-9 |v| sqrt(sum p^2)
     slack = 1e-3 if mfma else 2e-5
     for i in range(n):

@@ -66,11 +66,8 @@ def test_gemm_bias_residual(oracle):
 def test_gemm_tile_variants(oracle, tile):
     M, N, K = 515, 200, 96
     A, W, b = u(12, (M, K), 1.0), u(13, (N, K), 0.1), u(14, (N,), 0.1)
-    B.lib().vithip_gemm_set_tile(tile)
-    try:
-        close(B.gemm(A, W, b), oracle.linear(A, W, b))
-    finally:
-        B.lib().vithip_gemm_set_tile(0)
+    close(B.gemm(A, W, b, tile=tile), oracle.linear(A, W, b))
+    close(B.gemm(A, W, b, tile=tile, group_m=1), oracle.linear(A, W, b))
 
 
 def test_gemm_rejects_bad_k():

@@ -32,6 +32,21 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/*.h but not exported: {missing}"
 
 
+def test_product_library_has_no_probe_entry_points_or_tuning_setters():
+    """Instrumented kernels and process-wide tuning overrides live in the probe build only (csrc/vit_probes.h,
+    `make probes` -> libvit_mi355x_probe.so); the product library keeps no mutable process-wide state."""
+    import subprocess
+    product = os.path.join(os.path.dirname(B.LIB_PATH), "libvit_mi355x.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", product], capture_output=True, text=True, check=True).stdout
+    names = {ln.split()[-1] for ln in syms.splitlines() if ln.strip()}
+    banned = [n for n in names if n.startswith("vithip_probe_") or n.endswith("_set_debug_buffer") or
+              re.fullmatch(r"vithip_\w+_set_(tile|group|variant|sync|stagger|max_workgroups|mfma)", n)]
+    assert not banned, banned
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "vision-transformer-opencl_amd", "csrc", "vit_probes.h")).read(), flags=re.S)
+    probe_decl = set(re.findall(r"^int (\w+)\(", text, flags=re.M))
+    assert probe_decl and not (probe_decl & names)
+
+
 def test_rounding_is_c_roundf_half_away_from_zero():
     # ties at +-x.5e-6 must move away from zero (Network.c:185 uses roundf, not rint)
     x = np.array([0.5e-6, -0.5e-6, 1.5e-6, 2.5e-6, -2.5e-6, 0.1234564, 0.1234565, 0.1234566, 3.0, -7.25], np.float32)

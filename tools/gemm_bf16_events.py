@@ -25,12 +25,12 @@ dC = B.DeviceArray((M_, N), np.float32 if epi == 2 else np.uint16)
 dbg = B.DeviceArray((8 * 512,), np.uint32)
 args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi)
 B.hip_check(L.vithip_gemm_bf16_set_debug_buffer(dbg.ptr))
-B.gemm_bf16_set_variant(4)
+L.vithip_gemm_bf16_set_variant(4)
 L.vithip_gemm_bf16_set_max_workgroups(max_wgs)
 for _ in range(3):
     B.hip_check(L.vithip_gemm_bf16(None, C.byref(args)))
 ev = dbg.numpy().reshape(8, 512)
-B.gemm_bf16_set_variant(0)
+L.vithip_gemm_bf16_set_variant(0)
 nk = K // 64
 print(f"max workgroups {max_wgs or 'all'}")
 print(f"{name}: M={M_} N={N} K={K}, {nk} K steps per tile; times in cycles since the wave's first event")

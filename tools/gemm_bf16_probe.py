@@ -17,7 +17,7 @@ if len(sys.argv) > 2 and sys.argv[2] in ("stagger", "sync"):
             L.vithip_gemm_bf16_set_sync(st)
         else:
             L.vithip_gemm_bf16_set_stagger(st)
-        B.gemm_bf16_set_variant(2)
+        L.vithip_gemm_bf16_set_variant(2)
         out = {}
         for name, (M_, N, K, epi) in SHAPES.items():
             rng = np.random.default_rng(0)
@@ -34,7 +34,7 @@ if len(sys.argv) > 2 and sys.argv[2] in ("stagger", "sync"):
         print(json.dumps({sys.argv[2]: st, "tflops": out}))
     L.vithip_gemm_bf16_set_stagger(0)
     L.vithip_gemm_bf16_set_sync(1)
-    B.gemm_bf16_set_variant(0)
+    L.vithip_gemm_bf16_set_variant(0)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "probe":  # timing-only builds on the qkv shape: 101 = no DMA in loop, 102 = DMA only
     SHAPES = {"qkv": (M, 2304, 768, 0), "pp_no_dma": (M, 2304, 768, 201), "pp_no_mfma": (M, 2304, 768, 202), "pp_no_reads": (M, 2304, 768, 203), "pp_no_epilogue": (M, 2304, 768, 204), "pp_K3072": (M, 2304, 3072, 0), "pp_K3072_no_epi": (M, 2304, 3072, 204),
@@ -53,10 +53,10 @@ for name, (M_, N, K, epi) in SHAPES.items():
     args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if out_f32 else None, N, dC.ptr, N, M_, N, K, epi)
     res = {}
     for variant in ((1,) if epi > 2 else (1, 2, 1, 2)):  # interleaved A/B in one process (clocks differ per device/run)
-        B.gemm_bf16_set_variant(variant)
+        L.vithip_gemm_bf16_set_variant(variant)
         ms = [timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=3, warm=1) for _ in range(3)]
         res.setdefault("two-stage" if variant == 1 else "ping-pong", []).append(round(2.0 * M_ * N * K / (min(ms) * 1e-3) / 1e12, 1))
-    B.gemm_bf16_set_variant(0)
+    L.vithip_gemm_bf16_set_variant(0)
     print(json.dumps({name: {"tflops": res}}))
     for d in (dA, dW, db, dC):
         d.free()

@@ -22,8 +22,8 @@ for (M, N, K) in [(256 * 37 + 19, 2052, 192), (256 * 80, 1024, 128), (256 * 150,
     dR = B.DeviceArray.from_numpy(rng.uniform(-2, 2, (M, N)).astype(np.float32))
     for epi in (0, 1, 2):
         for one_barrier in (True, False):
-            B.gemm_bf16_set_variant(2)
-            B.gemm_bf16_set_sync(one_barrier)
+            L.vithip_gemm_bf16_set_variant(2)
+            L.vithip_gemm_bf16_set_sync(1 if one_barrier else 0)
             dC = B.DeviceArray((M, N), np.float32 if epi == 2 else np.uint16)
             args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if epi == 2 else None, N, dC.ptr, N, M, N, K, epi)
             first, diffs = None, 0
@@ -39,7 +39,7 @@ for (M, N, K) in [(256 * 37 + 19, 2052, 192), (256 * 80, 1024, 128), (256 * 150,
             dC.free()
     for d in (dA, dW, db, dR):
         d.free()
-B.gemm_bf16_set_variant(0)
-B.gemm_bf16_set_sync(True)
+L.vithip_gemm_bf16_set_variant(0)
+L.vithip_gemm_bf16_set_sync(1)
 print("RACE SCREEN", "FAILED" if bad else "clean")
 sys.exit(1 if bad else 0)

@@ -26,10 +26,10 @@ dC = B.DeviceArray((M_, N), np.float32 if epi == 2 else np.uint16)
 dbg = B.DeviceArray((8 * 32,), np.uint64)
 args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi)
 B.hip_check(L.vithip_gemm_bf16_set_debug_buffer(dbg.ptr))
-B.gemm_bf16_set_variant(3)
+L.vithip_gemm_bf16_set_variant(3)
 for _ in range(3):
     B.hip_check(L.vithip_gemm_bf16(None, C.byref(args)))
-B.gemm_bf16_set_variant(0)
+L.vithip_gemm_bf16_set_variant(0)
 s = dbg.numpy().reshape(8, 32).astype(np.int64) & 0xffffffff
 d = lambda x, y: int((x - y) & 0xffffffff)
 print(f"{name}: M={M_} N={N} K={K}  (cycles of the s_memtime clock)")

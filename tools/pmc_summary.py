@@ -97,8 +97,19 @@ def main():
             continue
         by_name[bench_key(r[0])][0] += r[5] * r[2]
         by_name[bench_key(r[0])][1] += r[2]
+    import datetime
+    import os
+    import subprocess
+    try:   # provenance: bench.py marks these figures as replayed (roofline.replayed_from)
+        dev = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
+        dev = next((ln.split(":", 1)[1].strip() for ln in dev.splitlines() if "Marketing Name" in ln and "AMD Instinct" in ln or
+                    ("Marketing Name" in ln and "Radeon" in ln)), None)
+    except Exception:
+        dev = None
     with open(out + ".json", "w") as f:
         json.dump({"unit": "bytes per launch", "batch": batch, "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
+                   "device": dev, "commit": os.environ.get("VIT_COMMIT"),
+                   "collected": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
                    "kernels": {k: round(v[0] / v[1]) for k, v in by_name.items()}}, f, indent=1)
     for r in rows[:12]:
         print(f"{r[5] / 1e6:9.1f} MB/launch  x{r[2]:4d}  {r[0]}")

@@ -14,7 +14,8 @@ import numpy as np
 from .synth import ModelConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvit_mi355x.so")
+# VIT_HIP_LIBRARY: the probe build (make probes -> libvit_mi355x_probe.so) for the tools/ scripts; default = the product
+LIB_PATH = os.environ.get("VIT_HIP_LIBRARY") or os.path.join(HERE, "libvit_mi355x.so")
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int)
@@ -47,7 +48,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
-                ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int)]
+                ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -64,7 +65,7 @@ class CGemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("epilogue", C.c_int)]
+                ("epilogue", C.c_int), ("tile", C.c_int), ("group_m", C.c_int)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -203,15 +204,15 @@ class DeviceArray:
             pass
 
 
-def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS) -> np.ndarray:
-    """C = epilogue(A . W^T + bias) through vithip_gemm_f32."""
+def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: int = 0) -> np.ndarray:
+    """C = epilogue(A . W^T + bias) through vithip_gemm_f32 (tile / group_m: per-call tuning fields, 0 = auto)."""
     A, W, bias = _as_f32(A), _as_f32(W), _as_f32(bias)
     M, K = A.shape
     N = W.shape[0]
     dA, dW, db = DeviceArray.from_numpy(A), DeviceArray.from_numpy(W), DeviceArray.from_numpy(bias)
     dC = DeviceArray((M, N))
     dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
-    args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue)
+    args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue, tile, group_m)
     hip_check(lib().vithip_gemm_f32(None, C.byref(args)), "vithip_gemm_f32")
     return dC.numpy()
 
@@ -219,7 +220,8 @@ def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS) -> np.ndarray:
 class CGemmBf16Args(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int), ("bias", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
-                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int)]
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
+                ("variant", C.c_int), ("two_barriers", C.c_int), ("stagger", C.c_int)]
 
 
 BF16_EPI_BF16, BF16_EPI_BF16_GELU, BF16_EPI_F32_RESIDUAL = 0, 1, 2
@@ -246,8 +248,10 @@ def f32_to_bf16_device(x: np.ndarray) -> np.ndarray:
     return dy.numpy()
 
 
-def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16) -> np.ndarray:
-    """vithip_gemm_bf16 on bf16 bit patterns; returns bf16 bits (uint16) or fp32 for the residual epilogue."""
+def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16, variant: int = 0, two_barriers: bool = False,
+              stagger: int = 0) -> np.ndarray:
+    """vithip_gemm_bf16 on bf16 bit patterns; returns bf16 bits (uint16) or fp32 for the residual epilogue.
+    variant: 0 auto, 1 two-stage kernel, 2 ping-pong kernel (fails for K < 128); two_barriers: its other barrier schedule."""
     L = lib()
     L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(CGemmBf16Args)]
     M, K = A_bits.shape
@@ -257,19 +261,10 @@ def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16) -> np
     out_f32 = epilogue == BF16_EPI_F32_RESIDUAL
     dC = DeviceArray((M, N), np.float32 if out_f32 else np.uint16)
     dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
-    args = CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue)
+    args = CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue,
+                         variant, 1 if two_barriers else 0, stagger)
     hip_check(L.vithip_gemm_bf16(None, C.byref(args)), "vithip_gemm_bf16")
     return dC.numpy()
-
-
-def gemm_bf16_set_variant(variant: int) -> None:
-    """0 auto, 1 two-stage kernel, 2 ping-pong kernel (fails for K < 128)."""
-    hip_check(lib().vithip_gemm_bf16_set_variant(int(variant)), "vithip_gemm_bf16_set_variant")
-
-
-def gemm_bf16_set_sync(one_barrier: bool) -> None:
-    """Barrier schedule of the ping-pong kernel: True (default) one barrier per phase and wave, False two."""
-    hip_check(lib().vithip_gemm_bf16_set_sync(1 if one_barrier else 0), "vithip_gemm_bf16_set_sync")
 
 
 def layernorm_bf16out(x, gamma, beta) -> np.ndarray:
@@ -286,14 +281,14 @@ def layernorm_bf16out(x, gamma, beta) -> np.ndarray:
     return dy.numpy()
 
 
-def attention_bf16io(qkv_bits, n_images: int, tokens: int, heads: int) -> np.ndarray:
-    """vithip_attention_bf16io on bf16 bit patterns -> bf16 bits."""
+def attention_bf16io(qkv_bits, n_images: int, tokens: int, heads: int, f32math: bool = False) -> np.ndarray:
+    """vithip_attention_bf16io (bf16 MFMA) or vithip_attention_bf16io_f32math (fp32 arithmetic) -> bf16 bits."""
     D = heads * 64
-    L = lib()
-    L.vithip_attention_bf16io.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    fn = getattr(lib(), "vithip_attention_bf16io_f32math" if f32math else "vithip_attention_bf16io")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     dq = DeviceArray.from_numpy(np.ascontiguousarray(qkv_bits, np.uint16))
     do = DeviceArray((n_images * tokens, D), np.uint16)
-    hip_check(L.vithip_attention_bf16io(None, dq.ptr, do.ptr, n_images, tokens, heads), "vithip_attention_bf16io")
+    hip_check(fn(None, dq.ptr, do.ptr, n_images, tokens, heads), "vithip_attention_bf16io")
     return do.numpy()
 
 
@@ -381,12 +376,13 @@ class Engine:
     """vit_engine (include/vit_engine.h): weights resident in HBM, batched forward."""
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
-                 lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False):
+                 lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False,
+                 gemm_tile: int = 0):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
         opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
-                       1 if prune_last_layer else 0, 1 if use_graph else 0)
+                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

@@ -18,6 +18,9 @@
 #include <hip/hip_runtime.h>
 
 #include "vit_hip_kernels.h"
+#ifdef VIT_PROBES
+#include "vit_probes.h"
+#endif
 
 namespace {
 
@@ -53,8 +56,11 @@ constexpr int K_LD = HD + 4;    // padded K row (floats): conflict-free ds_read_
 constexpr int ATT_THREADS = 512;
 constexpr int ATT_WAVES = ATT_THREADS / 64;
 
-unsigned long long *g_attn_dbg = nullptr;  // see vithip_attention_set_debug_buffer()
-int g_attn_bf16_mfma = 1;                  // see vithip_attention_bf16_set_mfma()
+#ifdef VIT_PROBES
+unsigned long long *g_attn_dbg = nullptr;  // see vithip_attention_set_debug_buffer() (probe build only)
+#else
+constexpr unsigned long long *g_attn_dbg = nullptr;
+#endif
 
 template <int NKT, typename IO>  // NKT = number of 32-key tiles: tokens <= 32*NKT; IO = float or bf16 bits
 __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(const IO *__restrict__ qkv,
@@ -793,11 +799,13 @@ int attention_dispatch(hipStream_t s, const IO *qkv, IO *out, int n_images, int 
 
 }  // namespace
 
+#ifdef VIT_PROBES
 // Probe hook: 8 x u64 cycle stamps per (image, head) workgroup; nullptr (default) disables them.
 extern "C" int vithip_attention_set_debug_buffer(void *buf) {
     g_attn_dbg = static_cast<unsigned long long *>(buf);
     return 0;
 }
+#endif
 
 extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, float *out,
                                     int n_images, int tokens, int heads) {
@@ -807,11 +815,18 @@ extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, fl
 // bf16 variant: qkv and out hold bf16 bits; K/V are widened to fp32 while staged into LDS and all
 // arithmetic (fp32 MFMA, softmax) is the same as above; the output is rounded to bf16 once.
 static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images, int tokens,
-                              int heads, int q_rows);
+                              int heads, int q_rows, bool bf16_mfma = true);
 
 extern "C" int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
                                        int n_images, int tokens, int heads) {
     return attention_bf16io_q(stream, qkv, out, n_images, tokens, heads, tokens);
+}
+
+// Same I/O, fp32 arithmetic: K/V widened to fp32 in LDS, both products on the fp32 matrix pipe (the cross-check of the
+// bf16-MFMA kernel: only the final rounding of the output to bf16 differs from vithip_attention_f32).
+extern "C" int vithip_attention_bf16io_f32math(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
+                                               int n_images, int tokens, int heads) {
+    return attention_bf16io_q(stream, qkv, out, n_images, tokens, heads, tokens, false);
 }
 
 // Only the first q_rows query rows of every image (the class token for q_rows = 1; tokens <= 224): used by the engine's
@@ -829,13 +844,13 @@ extern "C" int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsign
 }
 
 static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images, int tokens,
-                              int heads, int q_rows) {
+                              int heads, int q_rows, bool bf16_mfma) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (q_rows <= 0 || q_rows > tokens) return static_cast<int>(hipErrorInvalidValue);
     if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0 || (reinterpret_cast<size_t>(qkv) & 15) ||
         (reinterpret_cast<size_t>(out) & 15))
         return static_cast<int>(hipErrorInvalidValue);
-    if (g_attn_bf16_mfma) {  // bf16 matrix path while K/V of a head fit LDS; longer sequences use the chunked kernel
+    if (bf16_mfma) {  // bf16 matrix path while K/V of a head fit LDS; longer sequences use the chunked kernel
         switch ((tokens + 31) / 32) {
             case 1: return launch_bf16<1>(s, qkv, out, n_images, tokens, heads, q_rows);
             case 2: return launch_bf16<2>(s, qkv, out, n_images, tokens, heads, q_rows);
@@ -853,10 +868,4 @@ static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv,
         }
     }
     return attention_dispatch<bf16_t>(s, qkv, out, n_images, tokens, heads, q_rows);
-}
-
-// Tuning/test hook: 0 = keep the fp32-MFMA kernel for bf16 I/O, 1 (default) = bf16 MFMA attention.
-extern "C" int vithip_attention_bf16_set_mfma(int on) {
-    g_attn_bf16_mfma = on ? 1 : 0;
-    return 0;
 }

@@ -28,6 +28,9 @@
 //  * The implicit-GEMM variant (patch embedding) gathers A straight from NCHW images and
 //    fuses "+ pos_emb" and the token-row remap into the store.
 #include "vit_gemm_common.hpp"
+#ifdef VIT_PROBES
+#include "vit_probes.h"
+#endif
 
 namespace vitgemm {
 int launch_persistent(hipStream_t stream, GemmParams &p, int epilogue, int group_m);  // vit_gemm_persistent.hip
@@ -38,9 +41,14 @@ namespace {
 
 using namespace vitgemm;
 
-int g_gemm_tile = 0;   // 0 = auto; see vithip_gemm_set_tile()
-int g_gemm_group = 8;  // tile rows per L2 group; see vithip_gemm_set_group()
+// The product library carries NO mutable process-wide state: tile shape and L2 group size are per-call fields of
+// vithip_gemm_args (0 = auto).  Only the probe build (make probes, -DVIT_PROBES, libvit_mi355x_probe.so) has the
+// process-wide overrides the tools/ scripts flip between timings, and the timing-only kernel variants.
+#ifdef VIT_PROBES
+int g_gemm_tile = 0;   // 0 = no override; see vithip_gemm_set_tile()
+int g_gemm_group = 0;  // 0 = no override; see vithip_gemm_set_group()
 unsigned long long *g_gemm_dbg = nullptr;  // stamp buffer of the DBG == 5 probe
+#endif
 
 // DBG != 0 builds timing-only probes (tools/gemm_probe.py): 1 = no global loads and no LDS stores in
 // the K loop, 2 = no global loads, 3 = no LDS stores, 4 = as 1 without the barrier.  Results are wrong
@@ -309,7 +317,6 @@ template <int BM, int BN, int WM, int WN, int AMODE, int BK = 32, bool PIPE = fa
 int launch_tile(hipStream_t stream, GemmParams &p, int epilogue) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    p.group_m = g_gemm_group;
     const dim3 grid(p.tiles_m * p.tiles_n), block(256);
     if constexpr (AMODE == A_PATCHES) {
         hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS, A_PATCHES, 0, BK>), grid, block, 0, stream, p);
@@ -331,44 +338,49 @@ int launch_tile(hipStream_t stream, GemmParams &p, int epilogue) {
     return static_cast<int>(hipGetLastError());
 }
 
-
+#ifdef VIT_PROBES
 template <int DBG, int EPI = VITHIP_EPI_BIAS, bool PIPE = false>
 int launch_probe(hipStream_t stream, GemmParams &p) {
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = (p.N + 127) / 128;
-    p.group_m = g_gemm_group;
     hipLaunchKernelGGL((gemm_f32_nt_kernel<128, 128, 64, 64, EPI, A_DENSE, DBG, 32, PIPE>),
                        dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
     return static_cast<int>(hipGetLastError());
 }
+#endif
 
 template <int AMODE>
-int dispatch(hipStream_t stream, GemmParams &p, int epilogue) {
+int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int group_m) {
+    p.group_m = group_m > 0 ? group_m : 8;  // tile rows per L2 group of the XCD-aware walk
+#ifdef VIT_PROBES
+    if (g_gemm_tile) tile = g_gemm_tile;
+    if (g_gemm_group) p.group_m = g_gemm_group;
     if constexpr (AMODE == A_DENSE) {
-        switch (g_gemm_tile) {  // timing-only probes, never selected by the engine
+        switch (tile) {  // timing-only probes, never selected by the engine
             case 101: return launch_probe<1>(stream, p);
             case 102: return launch_probe<2>(stream, p);
             case 103: return launch_probe<3>(stream, p);
             case 104: return launch_probe<4>(stream, p);
             case 105: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5>(stream, p) : static_cast<int>(hipErrorInvalidValue);
-            case 129: p.dbg = g_gemm_dbg; return g_gemm_dbg ? vitgemm::launch_persistent_stamped(stream, p, epilogue, g_gemm_group) : static_cast<int>(hipErrorInvalidValue);
+            case 129: p.dbg = g_gemm_dbg; return g_gemm_dbg ? vitgemm::launch_persistent_stamped(stream, p, epilogue, p.group_m) : static_cast<int>(hipErrorInvalidValue);
             case 125: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5, VITHIP_EPI_BIAS, true>(stream, p) : static_cast<int>(hipErrorInvalidValue);
             case 126: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5, VITHIP_EPI_BIAS_GELU, true>(stream, p) : static_cast<int>(hipErrorInvalidValue);
             default: break;
         }
     }
+#endif
     if constexpr (AMODE == A_PATCHES) {
         // 0.7 % of the FLOPs: one moderate-register instantiation is enough (the gather indices and
         // the token-row remap of the fused epilogue cost ~40 VGPRs on top of the dense kernel)
         return launch_tile<128, 64, 64, 32, A_PATCHES>(stream, p, epilogue);
     }
-    switch (g_gemm_tile) {
+    switch (tile) {
         case 2: return launch_tile<256, 128, 128, 64, AMODE>(stream, p, epilogue);
         case 3: return launch_tile<128, 64, 64, 32, AMODE>(stream, p, epilogue);
         case 4: return launch_tile<128, 128, 64, 64, AMODE, 16>(stream, p, epilogue);
         case 5: return launch_tile<128, 64, 64, 32, AMODE, 16>(stream, p, epilogue);
         case 1: return launch_tile<128, 128, 64, 64, AMODE>(stream, p, epilogue);       // classic K loop
-        case 9: return vitgemm::launch_persistent(stream, p, epilogue, g_gemm_group);   // persistent, cross-tile pipelined
+        case 9: return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);   // persistent, cross-tile pipelined
         case 6: return launch_tile<128, 128, 64, 64, AMODE, 16, true>(stream, p, epilogue);
         case 7: return launch_tile<256, 128, 128, 64, AMODE, 32, true>(stream, p, epilogue);
         case 8: return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
@@ -386,7 +398,7 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue) {
                 return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
             }
             if (tiles < 2048) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
-            return vitgemm::launch_persistent(stream, p, epilogue, g_gemm_group);
+            return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
         }
     }
 }
@@ -397,7 +409,8 @@ bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) ==
 
 extern "C" {
 
-// Tuning hook (bench/tests): 0/1 = 128x128, 2 = 256x128, 3 = 128x64 workgroup tiles.
+#ifdef VIT_PROBES
+// Probe build only: process-wide overrides of the per-call tile / group fields (0 = none).
 int vithip_gemm_set_tile(int tile) {
     if ((tile < 0 || tile > 10) && (tile < 101 || tile > 129)) return static_cast<int>(hipErrorInvalidValue);
     g_gemm_tile = tile;
@@ -410,12 +423,12 @@ int vithip_gemm_set_debug_buffer(void *buf) {
     return 0;
 }
 
-// Tuning hook: tile rows per L2 group (1 = plain N-fastest order).
 int vithip_gemm_set_group(int group_m) {
-    if (group_m < 1 || group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
+    if (group_m < 0 || group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
     g_gemm_group = group_m;
     return 0;
 }
+#endif
 
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);
@@ -424,14 +437,15 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
         return static_cast<int>(hipErrorInvalidValue);
     if (!aligned16(a->A) || !aligned16(a->W)) return static_cast<int>(hipErrorInvalidValue);
     if ((size_t)a->M * a->lda * 4 >= 0x7fffffffull || (size_t)a->N * a->ldw * 4 >= 0x7fffffffull)
-        return static_cast<int>(hipErrorInvalidValue);  // 32-bit buffer offsets: split the batch (vit_engine does)
+        return static_cast<int>(hipErrorInvalidValue);  // 32-bit buffer offsets: split the batch (vit_engine's lane cap does)
     if (a->epilogue == VITHIP_EPI_BIAS_RESIDUAL && (!a->residual || a->ldr < a->N))
         return static_cast<int>(hipErrorInvalidValue);
     GemmParams p{};
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.R = a->residual; p.C = a->C;
     p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
     p.M = a->M; p.N = a->N; p.K = a->K;
-    return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue);
+    if (a->tile < 0 || a->tile > 10 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
+    return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue, a->tile, a->group_m);
 }
 
 int vithip_patch_embed_f32(vithip_stream_t stream, const float *images, const float *conv_w,
@@ -455,7 +469,7 @@ int vithip_patch_embed_f32(vithip_stream_t stream, const float *images, const fl
                        n_images, G * G + 1, embed_dim);
     int e = static_cast<int>(hipGetLastError());
     if (e) return e;
-    return dispatch<A_PATCHES>(s, p, VITHIP_EPI_BIAS);
+    return dispatch<A_PATCHES>(s, p, VITHIP_EPI_BIAS, 0, 0);
 }
 
 }  // extern "C"

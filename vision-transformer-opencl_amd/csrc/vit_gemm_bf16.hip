@@ -24,6 +24,9 @@
 //    store instead of scattering 2-byte elements.
 //  * Tile walk: XCD-aware remap + groups of 8 tile rows (as the fp32 kernel).
 #include "vit_gemm_common.hpp"
+#ifdef VIT_PROBES
+#include "vit_probes.h"
+#endif
 
 namespace {
 
@@ -298,12 +301,16 @@ __global__ void cls_rows_bf16path_kernel(const float *cls, const float *pos, flo
 }
 
 bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
-int g_cus = 0;      // CU count, queried once
-int g_variant = 0;  // 0 auto (ping-pong kernel when its preconditions hold), 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong
+int g_cus = 0;      // CU count, queried once (every device of a node is the same part)
+// Kernel variant, barrier schedule and start-up skew are per-call fields of vithip_gemm_bf16_args; the product library
+// has no mutable process-wide state.  The probe build (-DVIT_PROBES) adds process-wide overrides and instrumented kernels.
+#ifdef VIT_PROBES
+int g_variant = 0;  // 0 none, 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong, 4 event-log ping-pong
 unsigned long long *g_dbg = nullptr;
-int g_stagger = 0;
-int g_sync1 = 1;
-int g_max_wgs = 0;  // probe: cap on persistent workgroups (0 = one per CU)
+int g_stagger = -1;   // -1 = no override
+int g_sync1 = -1;     // -1 = no override
+int g_max_wgs = 0;    // cap on persistent workgroups (0 = one per CU)
+#endif
 
 }  // namespace
 
@@ -320,6 +327,7 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
     return static_cast<int>(hipGetLastError());
 }
 
+#ifdef VIT_PROBES
 int vithip_gemm_bf16_set_variant(int variant) {
     if (variant < 0 || variant > 4) return static_cast<int>(hipErrorInvalidValue);
     g_variant = variant;
@@ -327,12 +335,12 @@ int vithip_gemm_bf16_set_variant(int variant) {
 }
 
 int vithip_gemm_bf16_set_sync(int one_barrier) {
-    g_sync1 = one_barrier != 0;
+    g_sync1 = one_barrier < 0 ? -1 : (one_barrier != 0);
     return 0;
 }
 
 int vithip_gemm_bf16_set_stagger(int units) {
-    if (units < 0 || units > 64) return static_cast<int>(hipErrorInvalidValue);
+    if (units < -1 || units > 64) return static_cast<int>(hipErrorInvalidValue);
     g_stagger = units;
     return 0;
 }
@@ -346,6 +354,7 @@ int vithip_gemm_bf16_set_debug_buffer(void *buf) {
     g_dbg = static_cast<unsigned long long *>(buf);
     return 0;
 }
+#endif
 
 int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const unsigned short *conv_w16, const float *conv_b,
                             const float *cls, const float *pos, float *x, unsigned short *patches16, int n_images,
@@ -375,8 +384,8 @@ int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const u
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
     p.patches = P;
-    p.stagger = g_stagger;
-    p.sync1 = g_sync1;
+    p.stagger = 0;
+    p.sync1 = 1;
     if (g_cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -401,8 +410,15 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     p.tiles_m = (p.M + TBM - 1) / TBM;
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
-    p.stagger = g_stagger;
-    p.sync1 = g_sync1;
+    if (a->variant < 0 || a->variant > 2 || a->stagger < 0 || a->stagger > 64) return static_cast<int>(hipErrorInvalidValue);
+    p.stagger = a->stagger;
+    p.sync1 = a->two_barriers ? 0 : 1;
+    int variant = a->variant;
+#ifdef VIT_PROBES
+    if (g_variant) variant = g_variant;
+    if (g_stagger >= 0) p.stagger = g_stagger;
+    if (g_sync1 >= 0) p.sync1 = g_sync1;
+#endif
     if (g_cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -413,10 +429,13 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     // ping-pong kernel: needs two K steps per tile (its bias slot is recycled every second tile) and
     // operands addressable through 32-bit buffer offsets inside one tile (always true: 256 rows)
+#ifdef VIT_PROBES
     if (a->epilogue >= 201 && a->epilogue <= 204) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);  // timing probes
+#endif
     const bool pp_ok = p.K >= 2 * TBK && a->epilogue >= 0 && a->epilogue <= VITHIP_BF16_EPI_F32_RESIDUAL &&
                        (size_t)p.lda * 2 * 256 < (1u << 31) && (size_t)p.ldw * 2 * 256 < (1u << 31);
-    if (g_variant >= 2 && !pp_ok) return static_cast<int>(hipErrorInvalidValue);
+    if (variant >= 2 && !pp_ok) return static_cast<int>(hipErrorInvalidValue);
+#ifdef VIT_PROBES
     if (g_variant == 3) {
         if (!g_dbg) return static_cast<int>(hipErrorInvalidValue);
         p.dbg = g_dbg;
@@ -427,10 +446,13 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
         p.dbg = g_dbg;
         return vitgemm::launch_gemm_bf16_pp(s, p, 300 + a->epilogue, g_max_wgs ? g_max_wgs : g_cus);
     }
-    if (g_variant != 1 && pp_ok) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);
+#endif
+    if (variant != 1 && pp_ok) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);
     switch (a->epilogue) {
+#ifdef VIT_PROBES
         case 101: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 1>), grid, block, 0, s, p); break;
         case 102: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 2>), grid, block, 0, s, p); break;
+#endif
         case VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16_GELU>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_nt_kernel<VITHIP_BF16_EPI_F32_RESIDUAL>, grid, block, 0, s, p); break;

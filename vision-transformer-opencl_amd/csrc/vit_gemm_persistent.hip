@@ -269,6 +269,7 @@ int launch_persistent_tile(hipStream_t stream, GemmParams &p, int epilogue, int 
     return static_cast<int>(hipGetLastError());
 }
 
+#ifdef VIT_PROBES
 // Stamped probe build (tools/gemm_probe.py --stamp-tile 129): p.dbg receives 8 x u64 per workgroup.
 int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, int group_m) {
     if (g_persistent_wgs == 0) {
@@ -288,6 +289,8 @@ int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, i
         hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, VITHIP_EPI_BIAS, true>), grid, block, 0, stream, p);
     return static_cast<int>(hipGetLastError());
 }
+
+#endif
 
 // Entry used by vit_gemm.hip's dispatcher.  Needs at least 4 K steps per tile (K >= 128).
 int launch_persistent(hipStream_t stream, GemmParams &p, int epilogue, int group_m) {

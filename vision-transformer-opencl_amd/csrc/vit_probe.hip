@@ -4,9 +4,11 @@
 // per wave, to read the fp32 matrix rate (and so the clock) the chip sustains; the GEMM roofline
 // fraction in bench.py is quoted against the spec peak, this probe says how much of the gap is
 // the kernel's and how much the clock's.
+#ifdef VIT_PROBES  // whole file: probe build only (make probes -> libvit_mi355x_probe.so)
 #include <hip/hip_runtime.h>
 
 #include "vit_hip_kernels.h"
+#include "vit_probes.h"
 #include "vit_gemm_common.hpp"
 
 namespace {
@@ -170,3 +172,4 @@ extern "C" int vithip_probe_store(vithip_stream_t stream, void *out, int blocks,
                        static_cast<float4 *>(out), iters, mode, stride, static_cast<unsigned long long *>(cycles));
     return static_cast<int>(hipGetLastError());
 }
+#endif  // VIT_PROBES

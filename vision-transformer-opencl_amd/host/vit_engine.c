@@ -123,6 +123,7 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->dtype = VIT_DTYPE_F32;
     opt->prune_last_layer = 0;
     opt->use_graph = 0;
+    opt->gemm_tile = 0;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -411,6 +412,7 @@ static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int
     vithip_gemm_args a;
     a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
+    a.tile = e->opt.gemm_tile; a.group_m = 0;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_f32(s, &a));
     HIP_TRY(e, stage_end(e, s));
@@ -422,6 +424,7 @@ static int gemm16(vit_engine *e, vithip_stream_t s, int stage, const unsigned sh
     vithip_gemm_bf16_args a;
     a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
+    a.variant = 0; a.two_barriers = 0; a.stagger = 0;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_bf16(s, &a));
     HIP_TRY(e, stage_end(e, s));
