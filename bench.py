@@ -35,7 +35,7 @@ STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it
     "qkv": "gemm_f32_nt_persistent_kernel<EPI_BIAS>", "head": "gemm_f32_nt_persistent_kernel<EPI_BIAS>",
     "fc1": "gemm_f32_nt_persistent_kernel<EPI_BIAS_GELU>",
     "outproj": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>",
-    "attn": "attention_f32_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
+    "attn": "attention_f32_resident_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
     "softmax": "softmax_top1_f32_kernel",
 }
 

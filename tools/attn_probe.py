@@ -17,14 +17,20 @@ flop = 2.0 * n * 2 * heads * T * T * 64
 print(json.dumps({"attention_ms": [round(m, 4) for m in ms], "tflops": round(flop / (min(ms) * 1e-3) / 1e12, 1)}))
 
 import ctypes as C
-dbg = B.DeviceArray((n * heads, 8), np.uint64)
+# probe build: 8 cycle stamps per wave of every persistent workgroup's second (image, head) item
+dbg = B.DeviceArray((256 * 8, 8), np.uint64)
 L.vithip_attention_set_debug_buffer.argtypes = [C.c_void_p]
 L.vithip_attention_set_debug_buffer(dbg.ptr)
 for _ in range(2):
     B.hip_check(L.vithip_attention_f32(None, dq.ptr, do.ptr, n, T, heads))
-d = dbg.numpy().astype(np.int64)
+d = dbg.numpy().astype(np.int64).reshape(256, 8, 8)
 L.vithip_attention_set_debug_buffer(None)
-med = lambda a: int(np.median(a))
-print(json.dumps({"wave0_cycles_median": {"stage_kv": med(d[:, 1] - d[:, 0]), "qk": med(d[:, 2] - d[:, 1]),
-                                          "softmax": med(d[:, 3] - d[:, 2]), "pv": med(d[:, 4] - d[:, 3]),
-                                          "store": med(d[:, 5] - d[:, 4]), "total": med(d[:, 5] - d[:, 0])}}))
+for mode in (1, 2, 3, 4, 8, 15):
+    L.vithip_attention_set_probe_mode(mode)
+    m = min(timed(lambda: B.hip_check(L.vithip_attention_f32(None, dq.ptr, do.ptr, n, T, heads)), reps=5, warm=2) for _ in range(3))
+    print(json.dumps({"probe_mode": mode, "ms": round(m, 4)}))
+L.vithip_attention_set_probe_mode(0)
+names = ["s_jobA", "s_job2", "wait_barrier1", "pv_jobA", "pv_job2", "wait_barrier2"]
+for w in range(8):
+    seg = np.median(d[:, w, 1:7] - d[:, w, 0:6], axis=0).astype(int)
+    print(json.dumps({"wave": w, **dict(zip(names, seg.tolist())), "item_total": int(np.median(d[:, w, 6] - d[:, w, 0]))}))

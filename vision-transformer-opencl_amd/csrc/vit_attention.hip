@@ -17,10 +17,20 @@
 // The softmax normaliser is applied to O (32 values per lane) instead of P (112 per lane).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "vit_hip_kernels.h"
 #ifdef VIT_PROBES
 #include "vit_probes.h"
 #endif
+
+namespace vitattn {
+#ifdef VIT_PROBES
+extern unsigned long long *g_res_dbg;
+extern int g_res_mode;
+#endif
+int attention_f32_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows);  // vit_attention_resident.hip
+}
 
 namespace {
 
@@ -780,6 +790,10 @@ int attention_dispatch(hipStream_t s, const IO *qkv, IO *out, int n_images, int 
     if ((reinterpret_cast<size_t>(qkv) & 15) || (reinterpret_cast<size_t>(out) & 15))
         return static_cast<int>(hipErrorInvalidValue);
     const int nkt = (tokens + 31) / 32;
+    if constexpr (std::is_same<IO, float>::value) {
+        // fp32 I/O up to 224 tokens: the 16x16x4 kernel with LDS-DMA staging (vit_attention_resident.hip)
+        if (tokens <= 224) return vitattn::attention_f32_resident(s, qkv, out, n_images, tokens, heads, q_rows);
+    }
     switch (nkt) {
         case 1: return launch<1, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
         case 2: return launch<2, IO>(s, qkv, out, n_images, tokens, heads, q_rows);
@@ -800,9 +814,14 @@ int attention_dispatch(hipStream_t s, const IO *qkv, IO *out, int n_images, int 
 }  // namespace
 
 #ifdef VIT_PROBES
+extern "C" int vithip_attention_set_probe_mode(int mode) {
+    vitattn::g_res_mode = mode;
+    return 0;
+}
 // Probe hook: 8 x u64 cycle stamps per (image, head) workgroup; nullptr (default) disables them.
 extern "C" int vithip_attention_set_debug_buffer(void *buf) {
     g_attn_dbg = static_cast<unsigned long long *>(buf);
+    vitattn::g_res_dbg = g_attn_dbg;
     return 0;
 }
 #endif

@@ -1,0 +1,501 @@
+// csrc/vit_attention_resident.hip -- fp32 scaled-dot-product attention, K/V of one head resident in LDS (tokens <= 224).
+//
+// Reference: ViT_seq.c:156-215 (scores = q.k / sqrtf(head_dim); row softmax with max subtraction; head_out = P.V).
+// This is the kernel behind vithip_attention_f32 for ViT-B/16 (197 tokens); the first version (attention_f32_kernel in
+// vit_attention.hip, still used for the bf16-I/O cross-check variant) ran at 50 % of the fp32 matrix roofline.  What
+// the stamps of that kernel showed (tools/attn_probe.py, 73k cycles per (image, head) on a CU):
+//   * 197 tokens = 6 x 32 + 5: with 32x32 MFMA tiles a wave owns 32 query rows, 7 waves on 4 SIMDs make two SIMDs do
+//     two full blocks (one of them for 5 valid rows) and both products run over 224 padded keys;
+//   * staging the head's 100 KB of K/V (9.3k cycles) and the output stores (2k) had nothing to overlap with: the LDS
+//     holds one head, so one workgroup per CU, and it waited for its own loads.
+// This version:
+//   * v_mfma_f32_16x16x4_f32 (exact fp32, same rate as 32x32x2): 16-row query blocks and 16-key tiles, so 197 tokens
+//     pad to 208 keys and the work splits into 13 half-size blocks that are dealt to the 8 waves so that every SIMD gets
+//     3 - 3.5 blocks: waves 0-3 take two blocks, waves 4-7 one, and the odd 13th block (the 5 tail rows) is cut in two by
+//     KEYS between waves 4 and 5, whose partial softmax results (running max, sum, O) meet in LDS and are merged by
+//     wave 4 in a fixed order (deterministic, no atomics);
+//   * persistent workgroups (one per CU) walk the (image, head) items and stage by LDS-DMA (buffer_load ... lds: no
+//     registers, zero-fill past the last token by the buffer bounds) in the OTHER phase's shadow:
+//         [ S = K.Q^T + softmax of item i   ||  DMA V(i)   ]  barrier
+//         [ O = V^T.P^T of item i, stores   ||  DMA K(i+1), Q(i+1) -> registers ]  barrier
+//     K is dead once every wave has its scores, V once every wave has its output, so one LDS image of each suffices.
+//
+// MFMA mapping (lane = 16 g + n):
+//   S^T tile (16 keys x 16 queries) = K_tile . Q^T: A = K[key 16kt+n][d], B = Q[q0+n][d] with d = 16c + 4g + j for MFMA
+//       (c, j) -- the same permutation of d on both operands, chosen so that a lane reads its four j as one 16-byte word;
+//       accumulator register i of lane (n, g) = score(query q0+n, key 16kt + 4g + i): a softmax row is lane-local plus two
+//       lane exchanges (xor 16, xor 32).
+//   O^T (64 d x 16 queries) += V^T . P^T, 4 keys per MFMA: register i of the S^T tile IS the B operand (k = g selects
+//       key 16kt + 4g + i), A = V[that key][4n + j] for output tile j -- one 16-byte LDS read per 4 MFMAs -- and a lane
+//       ends up with O[q0+n][16g .. 16g+15]: four 16-byte stores.
+//   K rows are 256 B in LDS with their 16-byte chunks XOR-swizzled by (row & 15) on the SOURCE address of the DMA (the LDS
+//   side of an LDS-DMA is linear), which makes the A-fragment reads conflict-free; V is read a whole row per 16 lanes.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "vit_hip_kernels.h"
+
+namespace vitattn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int HD = 64;            // head_dim
+constexpr int ROWB = HD * 4;      // bytes of one K or V row in LDS
+constexpr int RES_WAVES = 8;
+constexpr int RES_THREADS = RES_WAVES * 64;
+constexpr int PART_LD = 68;       // floats per query row of a tail partial: 64 x O, max, sum, pad
+constexpr float kScale = 0.125f * 1.4426950408889634f;  // (1 / sqrtf(64)) * log2(e): p = exp2(s*kScale - max*kScale)
+
+template <int NKT>  // 16-key tiles: tokens <= 16 * NKT
+__global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(const float *__restrict__ qkv,
+                                                                             float *__restrict__ out, int tokens, int heads,
+                                                                             int n_items, int q_rows
+#ifdef VIT_PROBES
+                                                                             , unsigned long long *__restrict__ dbg, int mode
+#endif
+) {
+#ifndef VIT_PROBES
+    constexpr unsigned long long *dbg = nullptr;  // instrumentation exists in the probe build only
+    constexpr int mode = 0;
+#endif
+    // mode (probe build only, else 0): timing experiments with WRONG results: 1 = no softmax arithmetic, 2 = no LDS fragment
+    // reads, 4 = waves 4-7 idle, 8 = no LDS-DMA after the first item
+    // dbg != nullptr (probe build, tools/attn_probe.py): per wave 8 cycle stamps of the workgroup's SECOND item
+    constexpr int KEYS = NKT * 16;
+    constexpr int KH = (NKT + 1) / 2;  // key tiles [0, KH) and [KH, NKT) of a tail block split between two waves
+    __shared__ __attribute__((aligned(1024))) char lds[2 * KEYS * ROWB + 2 * 16 * PART_LD * 4];
+    char *const Ks = lds;
+    char *const Vs = lds + KEYS * ROWB;
+    float *const part = reinterpret_cast<float *>(lds + 2 * KEYS * ROWB);
+
+    // `tk` = tokens, made opaque once per item (asm below): hipcc otherwise hoists every tokens-dependent mask, predicate
+    // and tail-row offset of the unrolled job bodies out of the item loop -- ~60 VGPRs and 300 spilled SGPRs of invariants
+    int tk = tokens;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int D = heads * HD, ld = 3 * D;
+
+    // ---- which query blocks this wave owns (wave-uniform) -------------------------------------------------------
+    const int nblk = (q_rows + 15) >> 4;
+    const bool split = nblk > RES_WAVES && (nblk & 1);  // odd block count: the last block is cut in two by keys
+    const int nfull = split ? nblk - 1 : nblk;
+    const bool hasA = wave < nfull && !((mode & 4) && wave >= 4), hasB = wave + RES_WAVES < nfull;
+    const int ta = nblk - 1 - RES_WAVES;  // waves ta, ta + 1 share the tail block (ta <= 5 as nblk <= 14)
+    const bool isTa = split && wave == ta, isTb = split && wave == ta + 1;
+    const int blkA = wave, blkB = (isTa || isTb) ? nblk - 1 : wave + RES_WAVES;
+    const bool has2 = hasB || isTa || isTb;
+
+    // ---- LDS-DMA of one head's K or V: 4 rows (1 KB) per wave instruction, rows past the last token read as zero ---
+    const int row_in = lane >> 4, cpos = lane & 15;
+    auto dma = [&](const float *head_base, char *dst, bool swizzle) __attribute__((always_inline)) {
+        // bytes addressable through the descriptor: everything up to the end of the last token's 64 floats
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(head_base), 0, (tokens - 1) * ld * 4 + ROWB, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < (NKT * 4 + RES_WAVES - 1) / RES_WAVES; ++k) {
+            const int t = wave + RES_WAVES * k;  // 4-row group
+            if (t < NKT * 4) {
+                const int row = 4 * t + row_in;
+                const int chunk = swizzle ? (cpos ^ (row & 15)) : cpos;
+                // the whole offset sits in the per-lane operand: that is the one the descriptor's bounds check sees
+                const int voff = row * ld * 4 + chunk * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + t * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    auto item_base = [&](int item) -> const float * {
+        const int img = item / heads, head = item - img * heads;
+        return qkv + (size_t)img * tokens * ld + head * HD;
+    };
+    auto load_q = [&](const float *base, int blk, f32x4 (&qf)[4]) __attribute__((always_inline)) {
+        int qrow = blk * 16 + n;
+        qrow = qrow < tokens ? qrow : tokens - 1;  // rows past the end: clamped address, never stored
+        const float *src = base + (size_t)qrow * ld + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const f32x4 *>(src + 16 * c);
+    };
+
+    // per-lane LDS offsets
+    int koff[4];  // K fragment chunk c of this lane's row: byte offset inside the row, swizzled
+#pragma unroll
+    for (int c = 0; c < 4; ++c) koff[c] = ((4 * c + g) ^ n) * 16;
+    const char *const kbase = Ks + n * ROWB;
+    const char *const vbase = Vs + (4 * g) * ROWB + n * 16;
+
+    // ---- the sub-steps of a job = (NB query blocks, key tiles [KT0, KT1)) ---------------------------------------------
+    // A wave that owns two blocks runs them TOGETHER: every K / V fragment read from LDS feeds the MFMAs of both blocks
+    // (half the LDS reads per MFMA), and the two blocks are two independent accumulation chains -- v_mfma_f32_16x16x4_f32
+    // issues every 32 cycles but a DEPENDENT one only every 40 (MI355X_MICROARCH.md).  A single block takes its key tiles
+    // in pairs for the same reason.  Fragments are fetched one 16-deep chunk ahead of the MFMAs that use them.
+    auto s_mm = [&](auto nb_c, auto b0_c, auto kt0_c, auto kt1_c, const f32x4 (&qf)[2][4], f32x4 (&st)[2][NKT]) __attribute__((always_inline)) {
+        constexpr int B0 = decltype(b0_c)::value;  // first register set used (a single block may live in set 1)
+        constexpr int NB = decltype(nb_c)::value, KT0 = decltype(kt0_c)::value, KT1 = decltype(kt1_c)::value;
+        constexpr int TP = NB == 1 ? 2 : 1;                    // key tiles per step
+        constexpr int NS = (KT1 - KT0 + TP - 1) / TP;          // steps (the last may hold a single tile)
+        f32x4 kf[2][TP] = {};
+        auto read_kc = [&](int sidx, int c, int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                const int kt = KT0 + sidx * TP + u;
+                if (kt < KT1 && !(mode & 2)) kf[set][u] = *reinterpret_cast<const f32x4 *>(kbase + kt * (16 * ROWB) + koff[c]);
+            }
+        };
+        read_kc(0, 0, 0);
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+#pragma unroll
+            for (int u = 0; u < TP; ++u)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (KT0 + sidx * TP + u < KT1) st[B0 + b][KT0 + sidx * TP + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int step = 4 * sidx + c;  // running chunk index: buffer = step & 1
+                if (c < 3) read_kc(sidx, c + 1, (step + 1) & 1);
+                else if (sidx + 1 < NS) read_kc(sidx + 1, 0, (step + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int u = 0; u < TP; ++u)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const int kt = KT0 + sidx * TP + u;
+                            if (kt < KT1)
+                                st[B0 + b][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[step & 1][u][j], qf[B0 + b][c][j], st[B0 + b][kt], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // row softmax of one block over the job's keys (unnormalised: p = 2^((s - max) c); max and sum are returned).
+    // fp32 VALU work is paid for in matrix-pipe time on gfx950, so it is kept to max, one fma + v_exp_f32, add per score;
+    // keys >= tokens exist only in the last tile(s).
+    auto softmax = [&](auto kt0_c, auto kt1_c, f32x4 (&st)[NKT], float &m_out, float &l_out) __attribute__((always_inline)) {
+        constexpr int KT0 = decltype(kt0_c)::value, KT1 = decltype(kt1_c)::value;
+        if (mode & 1) { m_out = 0.f; l_out = 1.f; return; }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = KT0; kt < KT1; ++kt) {
+            if (16 * kt + 16 > tk) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st[kt][i] = (16 * kt + 4 * g + i) < tk ? st[kt][i] : -INFINITY;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, st[kt][i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mxs = -mx * kScale;
+        float sum = 0.0f;
+#pragma unroll
+        for (int kt = KT0; kt < KT1; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][i], kScale, mxs));  // exp2(-inf) = 0: masked keys
+                st[kt][i] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        m_out = mx;
+        l_out = sum;
+    };
+    auto pv_mm = [&](auto nb_c, auto b0_c, auto kt0_c, auto kt1_c, const f32x4 (&st)[2][NKT], f32x4 (&o)[2][4]) __attribute__((always_inline)) {
+        constexpr int B0 = decltype(b0_c)::value;
+        constexpr int NB = decltype(nb_c)::value, KT0 = decltype(kt0_c)::value, KT1 = decltype(kt1_c)::value;
+        constexpr int NG = (KT1 - KT0) * 4;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[B0 + b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // one 16-byte read feeds 4 NB MFMAs: reads run VA groups ahead so that their latency is covered
+        constexpr int VA = NB == 1 ? 3 : 2;
+        f32x4 vf[VA + 1] = {};
+        auto read_v = [&](int gi) __attribute__((always_inline)) {  // gi = 4 (kt - KT0) + i
+            if (!(mode & 2)) vf[gi % (VA + 1)] = *reinterpret_cast<const f32x4 *>(vbase + ((KT0 + (gi >> 2)) * 16 + (gi & 3)) * ROWB);
+        };
+#pragma unroll
+        for (int gi = 0; gi < VA && gi < NG; ++gi) read_v(gi);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi + VA < NG) read_v(gi + VA);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    o[B0 + b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[gi % (VA + 1)][j], st[B0 + b][KT0 + (gi >> 2)][gi & 3], o[B0 + b][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store_rows = [&](int item, int blk, const f32x4 (&o)[4], float scale) __attribute__((always_inline)) {
+        const int row = blk * 16 + n;
+        if (row < q_rows) {
+            const int img = item / heads, head = item - img * heads;
+            float *dst = out + ((size_t)img * tokens + row) * D + head * HD + 16 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 w;
+                w[0] = o[0][i] * scale; w[1] = o[1][i] * scale; w[2] = o[2][i] * scale; w[3] = o[3][i] * scale;
+                *reinterpret_cast<f32x4 *>(dst + 4 * i) = w;
+            }
+        }
+    };
+    auto write_partial = [&](int which, const f32x4 (&o)[4], float m, float l) __attribute__((always_inline)) {
+        float *p = part + (which * 16 + n) * PART_LD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 w;
+            w[0] = o[0][i]; w[1] = o[1][i]; w[2] = o[2][i]; w[3] = o[3][i];
+            *reinterpret_cast<f32x4 *>(p + 16 * g + 4 * i) = w;
+        }
+        if (g == 0) { p[64] = m; p[65] = l; }
+    };
+    // the two halves of a tail block, merged in a fixed order: O = (O0 a0 + O1 a1) / (l0 a0 + l1 a1), a = 2^((m - M) c)
+    auto merge_tail = [&](int item) __attribute__((always_inline)) {
+        const float *p0 = part + n * PART_LD, *p1 = part + (16 + n) * PART_LD;
+        const float m0 = p0[64], l0 = p0[65], m1 = p1[64], l1 = p1[65];
+        const float M = fmaxf(m0, m1);
+        const float a0 = __builtin_amdgcn_exp2f((m0 - M) * kScale), a1 = __builtin_amdgcn_exp2f((m1 - M) * kScale);
+        const float inv = 1.0f / (l0 * a0 + l1 * a1);
+        const int row = (nblk - 1) * 16 + n;
+        if (row < q_rows) {
+            const int img = item / heads, head = item - img * heads;
+            float *dst = out + ((size_t)img * tokens + row) * D + head * HD + 16 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(p0 + 16 * g + 4 * i);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p1 + 16 * g + 4 * i);
+                f32x4 w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = (u[q] * a0 + v[q] * a1) * inv;
+                *reinterpret_cast<f32x4 *>(dst + 4 * i) = w;
+            }
+        }
+    };
+
+    using std::integral_constant;
+    constexpr integral_constant<int, 0> c0{};
+    constexpr integral_constant<int, KH> ch{};
+    constexpr integral_constant<int, NKT> cn{};
+
+    // ---- persistent walk over the (image, head) items ----------------------------------------------------------------
+    int item = blockIdx.x;
+    const int step = gridDim.x;
+    if (item >= n_items) return;  // workgroup-uniform
+    // LDS-DMA is issued by the two waves with the least matrix work (one block each when there are 9+ blocks): an issue
+    // costs 60-185 cycles of the issuing wave (MI355X_MICROARCH.md) and the others are on the phase's critical path
+    const bool dma_wave = wave >= RES_WAVES - 2;
+    const int w0 = wave & 1;                       // this DMA wave takes the 4-row groups t = 2k + w0
+    constexpr int DMA_PER_WAVE = (NKT * 4 + 1) / 2;
+    // Per-lane source offsets of a group are (t & 3)-periodic apart from the group's row base, which goes into the
+    // instruction's scalar offset: two VGPRs for K (t & 3 = w0, 2 + w0), one for V.  Rows past the last token are not
+    // zero-filled here but CLAMPED to the last token (its values are finite, the keys are masked / weigh 0): no bounds
+    // check involved, and only the last groups pay per-lane arithmetic.
+    const int lane_row = row_in * ld * 4;
+    const int koffA = lane_row + ((cpos ^ ((w0) << 2 | row_in)) << 4);
+    const int koffB = lane_row + ((cpos ^ ((2 + w0) << 2 | row_in)) << 4);
+    const int voffV = lane_row + (cpos << 4);
+    auto dma2 = [&](const float *head_base, char *dst, bool swizzle) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < DMA_PER_WAVE; ++k) {
+            const int t = 2 * k + w0;  // 4-row group
+            if (t < NKT * 4) {
+                // tokens > 16 (NKT - 1): only the groups of the LAST key tile can reach past the last token
+                if (2 * k + 1 < 4 * (NKT - 1) || 4 * t + 3 < tk) {  // first part known at compile time; wave-uniform
+                    const int voff = swizzle ? ((k & 1) ? koffB : koffA) : voffV;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + t * 1024), 16, voff, t * 16 * ld, 0, 0);
+                } else {
+                    const int lrow = 4 * t + row_in;
+                    const int srow = lrow < tk ? lrow : tk - 1;
+                    const int voff = srow * ld * 4 + ((swizzle ? (cpos ^ (lrow & 15)) : cpos) << 4);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + t * 1024), 16, voff, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    constexpr integral_constant<int, 1> one{};
+    constexpr integral_constant<int, 2> two{};
+#ifdef VIT_PROBES
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RES_STAMP(k) do { if (dbg && iter == 1) ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RES_STAMP(k) do { } while (0)
+#endif
+
+    // The item loop exists twice, once per wave role, so that each role gets its own register allocation: a two-block
+    // wave is at the VGPR limit (104 score + 32 output registers) and does nothing but matrix work; the one-block waves
+    // have room for the tail block, the merge and the LDS-DMA.  Both loops execute the same barriers in the same order
+    // (s_barrier counts arrivals; which copy of the code a wave arrives from does not matter).
+    // The SIMD issues from its oldest ready wave first: waves 0-3 would run both their blocks at full speed while their
+    // SIMD partners (waves 4-7, each a single dependent-heavier stream) crawl, and then finish alone.  The partners go first.
+    if (!hasB) __builtin_amdgcn_s_setprio(2);
+    if (hasB) {
+        // ============================ role: two full blocks, fused =====================================================
+        f32x4 qf[2][4];
+        {
+            const float *base = item_base(item);
+            load_q(base, blkA, qf[0]);
+            load_q(base, blkB, qf[1]);
+            dma(base + D, Ks, true);  // the first K: by everybody, nothing to hide behind yet
+        }
+        __syncthreads();
+        int iter = 0;
+        for (;;) {
+            asm volatile("" : "+s"(tk));
+            RES_STAMP(0);
+            f32x4 st[2][NKT];
+            float mA, lA, mB, lB;
+            s_mm(two, c0, c0, cn, qf, st);
+            softmax(c0, cn, st[0], mA, lA);
+            RES_STAMP(1);
+            softmax(c0, cn, st[1], mB, lB);
+            RES_STAMP(2);
+            __syncthreads();  // every wave has its scores (K is dead) and V has landed
+            RES_STAMP(3);
+            const int next = item + step;
+            f32x4 o[2][4];
+            pv_mm(two, c0, c0, cn, st, o);
+            if (next < n_items) {  // Q of the next item (this role is at the register limit until here)
+                const float *nb = item_base(next);
+                load_q(nb, blkA, qf[0]);
+                load_q(nb, blkB, qf[1]);
+            }
+            store_rows(item, blkA, o[0], 1.0f / lA);
+            RES_STAMP(4);
+            store_rows(item, blkB, o[1], 1.0f / lB);
+            RES_STAMP(5);
+            __syncthreads();  // V is dead, K/Q of the next item have landed
+            RES_STAMP(6);
+            ++iter;
+            if (next >= n_items) break;
+            item = next;
+        }
+    } else {
+        // ============================ role: one block (or none), tail halves, LDS-DMA =================================
+        f32x4 qf[2][4];
+        {
+            const float *base = item_base(item);
+            if (hasA) load_q(base, blkA, qf[0]);
+            if (has2) load_q(base, blkB, qf[1]);
+            dma(base + D, Ks, true);
+        }
+        __syncthreads();
+        int tail_item = -1;  // wave ta: an item whose tail partials wait in LDS
+        int iter = 0;
+        for (;;) {
+            asm volatile("" : "+s"(tk));
+            RES_STAMP(0);
+            // ---- phase 1: scores + softmax (reads K); V(item) lands meanwhile
+            const float *base = item_base(item);
+            if (dma_wave && (!(mode & 8) || iter == 0)) dma2(base + 2 * D, Vs, false);
+            if (tail_item >= 0) {  // only wave ta
+                merge_tail(tail_item);
+                tail_item = -1;
+            }
+            f32x4 st[2][NKT];
+            float mA = 0.f, lA = 1.f, mB = 0.f, lB = 1.f;
+            if (hasA) {
+                s_mm(one, c0, c0, cn, qf, st);
+                softmax(c0, cn, st[0], mA, lA);
+            }
+            RES_STAMP(1);
+            if (isTa) { s_mm(one, one, c0, ch, qf, st); softmax(c0, ch, st[1], mB, lB); }  // the tail block's keys [0, KH)
+            else if (isTb) { s_mm(one, one, ch, cn, qf, st); softmax(ch, cn, st[1], mB, lB); }  // ... [KH, NKT)
+            RES_STAMP(2);
+            __syncthreads();
+            RES_STAMP(3);
+            // ---- phase 2: O = V^T . P^T (reads V); K and Q of the next item land meanwhile
+            const int next = item + step;
+            if (next < n_items) {  // workgroup-uniform
+                const float *nb = item_base(next);
+                if (dma_wave && !(mode & 8)) dma2(nb + D, Ks, true);
+                if (hasA) load_q(nb, blkA, qf[0]);  // consumed after the barrier below
+                if (has2) load_q(nb, blkB, qf[1]);
+            }
+            f32x4 o[2][4];
+            if (hasA) {
+                pv_mm(one, c0, c0, cn, st, o);
+                store_rows(item, blkA, o[0], 1.0f / lA);
+            }
+            RES_STAMP(4);
+            if (isTa) {
+                pv_mm(one, one, c0, ch, st, o);
+                write_partial(0, o[1], mB, lB);
+                tail_item = item;
+            } else if (isTb) {
+                pv_mm(one, one, ch, cn, st, o);
+                write_partial(1, o[1], mB, lB);
+            }
+            RES_STAMP(5);
+            __syncthreads();  // V is dead, the partials are visible, K/Q of the next item have landed
+            RES_STAMP(6);
+            ++iter;
+            if (next >= n_items) break;
+            item = next;
+        }
+        if (tail_item >= 0) merge_tail(tail_item);
+    }
+#undef RES_STAMP
+#ifdef VIT_PROBES
+    if (dbg && lane == 0) {
+        unsigned long long *d = dbg + ((size_t)blockIdx.x * RES_WAVES + wave) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = ts[k];
+    }
+#endif
+}
+
+#ifdef VIT_PROBES
+unsigned long long *g_res_dbg = nullptr;  // vithip_attention_set_debug_buffer (probe build): 8 stamps per wave
+int g_res_mode = 0;                       // vithip_attention_set_probe_mode
+#endif
+
+template <int NKT>
+int launch_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows, int cus) {
+    const int items = n_images * heads;
+    const int grid = items < cus ? items : cus;  // one workgroup per CU: the LDS holds one head
+#ifdef VIT_PROBES
+    hipLaunchKernelGGL(attention_f32_resident_kernel<NKT>, dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items, q_rows,
+                       g_res_dbg, g_res_mode);
+#else
+    hipLaunchKernelGGL(attention_f32_resident_kernel<NKT>, dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items, q_rows);
+#endif
+    return static_cast<int>(hipGetLastError());
+}
+
+// tokens <= 224, q_rows <= tokens.  Returns a hipError_t value.
+int attention_f32_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows) {
+    static int cus = 0;  // every device of a node is the same part
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return static_cast<int>(hipErrorInvalidDevice);
+        cus = v;
+    }
+    switch ((tokens + 15) / 16) {
+        case 1: return launch_resident<1>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 2: return launch_resident<2>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 3: return launch_resident<3>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 4: return launch_resident<4>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 5: return launch_resident<5>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 6: return launch_resident<6>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 7: return launch_resident<7>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 8: return launch_resident<8>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 9: return launch_resident<9>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 10: return launch_resident<10>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 11: return launch_resident<11>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 12: return launch_resident<12>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 13: return launch_resident<13>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        case 14: return launch_resident<14>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
+}  // namespace vitattn

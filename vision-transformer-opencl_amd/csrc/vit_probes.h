@@ -31,7 +31,10 @@ int vithip_gemm_bf16_set_stagger(int units);
 int vithip_gemm_bf16_set_max_workgroups(int n);   /* cap on persistent workgroups of the event-log build */
 int vithip_gemm_bf16_set_debug_buffer(void *buf);
 
-int vithip_attention_set_debug_buffer(void *buf); /* 8 x u64 cycle stamps per (image, head) workgroup; NULL disables */
+int vithip_attention_set_debug_buffer(void *buf);
+/* timing experiments of the resident fp32 attention kernel (results wrong by construction): bit 0 no softmax arithmetic,
+ * bit 1 no LDS fragment reads, bit 2 waves 4-7 idle, bit 3 no LDS-DMA after the first item */
+int vithip_attention_set_probe_mode(int mode); /* 8 x u64 cycle stamps per (image, head) workgroup; NULL disables */
 
 /* register-only fp32 MFMA loop; each wave issues iters*32 v_mfma_f32_32x32x2_f32 (4096 flop each) */
 int vithip_probe_mfma_f32(vithip_stream_t stream, float *out, int blocks, int threads, int iters);
