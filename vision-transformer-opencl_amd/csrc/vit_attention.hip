@@ -30,6 +30,7 @@ extern unsigned long long *g_res_dbg;
 extern int g_res_mode;
 #endif
 int attention_f32_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows);  // vit_attention_resident.hip
+int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads);  // vit_attention_stream.hip
 }
 
 namespace {
@@ -879,6 +880,9 @@ static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv,
             case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads, q_rows);
             case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads, q_rows);
             default: {
+                // 225..768 tokens (ViT-L/16-384: 577): all query blocks of a head in one persistent workgroup, K/V streamed
+                // once through an LDS-DMA ring (vit_attention_stream.hip); longer sequences: the chunked kernel below
+                if (tokens <= 768) return vitattn::attention_bf16_stream(s, qkv, out, n_images, tokens, heads);
                 const int qblocks = ((tokens + 31) / 32 + ATT_WAVES - 1) / ATT_WAVES;
                 hipLaunchKernelGGL(attention_bf16_chunked_kernel, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s, qkv,
                                    out, tokens, heads);
