@@ -62,12 +62,25 @@ def test_gemm_bias_residual(oracle):
     close(B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL), ref)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_gemm_tile_variants(oracle, tile):
     M, N, K = 515, 200, 96
     A, W, b = u(12, (M, K), 1.0), u(13, (N, K), 0.1), u(14, (N,), 0.1)
     close(B.gemm(A, W, b, tile=tile), oracle.linear(A, W, b))
     close(B.gemm(A, W, b, tile=tile, group_m=1), oracle.linear(A, W, b))
+
+
+def test_gemm_tile_shapes_are_bit_identical():
+    """The engine picks tile shapes by problem size (64x64 for one image, 128x64, 128x128 persistent ...) and documents
+    that a row's result does not depend on how many rows it is computed with (batch position, lanes, prune_last_layer):
+    every output must sum its k in the same order with the same MFMA whatever the tile."""
+    M, N, K = 333, 200, 768
+    A, W, b, R = u(40, (M, K), 1.0), u(41, (N, K), 0.1), u(42, (N,), 0.1), u(43, (M, N), 2.0)
+    for epi, res in ((B.EPI_BIAS, None), (B.EPI_BIAS_GELU, None), (B.EPI_BIAS_RESIDUAL, R)):
+        ref = B.gemm(A, W, b, residual=res, epilogue=epi, tile=1)
+        for tile in (0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+            assert np.array_equal(B.gemm(A, W, b, residual=res, epilogue=epi, tile=tile), ref), (epi, tile)
+        assert np.array_equal(B.gemm(A[:7], W, b, residual=None if res is None else res[:7], epilogue=epi), ref[:7]), epi
 
 
 def test_gemm_rejects_bad_k():

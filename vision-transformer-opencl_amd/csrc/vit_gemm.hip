@@ -385,6 +385,7 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
         case 7: return launch_tile<256, 128, 128, 64, AMODE, 32, true>(stream, p, epilogue);
         case 8: return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
         case 10: return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);  // pipelined
+        case 11: return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);    // one 32x32 accumulator per wave
         default: {
             // auto.  Large problems: the persistent walk wins where the epilogue is light on registers (bias, bias+GELU:
             // fc1 22.0 vs 23.0 ms per step); the residual epilogue needs 255 VGPRs there and is faster one tile per
@@ -393,6 +394,12 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
             // 32 / 64 / 128 (bench.py --batch B --gemm-tile 0|8): a single image 5.47 -> 3.64 ms, batch 64 +7 %; the
             // thresholds leave every GEMM of the batch-256 metric (>= 1182 tiles per lane) on the large-problem kernels.
             const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+            // Latency regime (the reference's own use is ONE image, Main.c:45-46): when even 128x64 tiles leave CUs without
+            // a workgroup, the time of a GEMM is one wave's K loop -- 2 accumulators x K/2 MFMAs of 64 cycles -- so 64x64
+            // tiles (one 32x32 accumulator per wave) halve it and quadruple the workgroups: fc2 of one image 110 -> 50 us.
+            // Every output still sums its k in the same order with the same instruction: results are bit-identical.
+            if ((long)((p.M + 127) / 128) * ((p.N + 63) / 64) < 256)
+                return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);
             if (epilogue == VITHIP_EPI_BIAS_RESIDUAL) {
                 if (tiles < 1024) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
                 return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
@@ -444,7 +451,7 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.R = a->residual; p.C = a->C;
     p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
     p.M = a->M; p.N = a->N; p.K = a->K;
-    if (a->tile < 0 || a->tile > 10 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
+    if (a->tile < 0 || a->tile > 11 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
     return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue, a->tile, a->group_m);
 }
 
