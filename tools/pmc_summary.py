@@ -41,7 +41,7 @@ def read_counter(dirname, counter):
 
 def short_name(name):
     """'void (anonymous namespace)::gemm_f32_nt_kernel<128, ...>(vitgemm::GemmParams)' -> 'gemm_f32_nt_kernel<128, ...>'"""
-    name = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("vitgemm::", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("vitgemm::", "").replace("vitattn::", "")
     cut = name.rfind("(")
     if cut > 0 and name.endswith(")"):
         name = name[:cut]
