@@ -102,8 +102,8 @@ def main():
     import subprocess
     try:   # provenance: bench.py marks these figures as replayed (roofline.replayed_from)
         dev = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
-        dev = next((ln.split(":", 1)[1].strip() for ln in dev.splitlines() if "Marketing Name" in ln and "AMD Instinct" in ln or
-                    ("Marketing Name" in ln and "Radeon" in ln)), None)
+        names = [ln.split(":", 1)[1].strip() for ln in dev.splitlines() if "Marketing Name" in ln]
+        dev = next((n for n in names if "Instinct" in n or "Radeon" in n or "MI3" in n), None)
     except Exception:
         dev = None
     with open(out + ".json", "w") as f:
