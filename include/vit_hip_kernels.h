@@ -150,6 +150,13 @@ int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const u
                             const float *conv_b, const float *cls, const float *pos, float *x,
                             unsigned short *patches16, int n_images, int img_size, int patch_size, int in_chans,
                             int embed_dim);
+/* The same result as ONE implicit GEMM that reads the NCHW fp32 images directly (pixels rounded to bf16 in the A-tile loader; no
+ * staging pass, no workspace).  A tested alternative, not the engine's default: 2.4 ms against 1.0 ms at batch 2048, bound by
+ * the fp32 pixel bytes every 128-wide N tile re-reads (csrc/vit_patch_embed_bf16.hip).
+ * Needs patch % 4 == 0, chans*patch^2 % 32 == 0, img % 4 == 0, n * patches <= 2^24. */
+int vithip_patch_embed_bf16_implicit(vithip_stream_t stream, const float *images, const unsigned short *conv_w16,
+                                     const float *conv_b, const float *cls, const float *pos, float *x,
+                                     int n_images, int img_size, int patch_size, int in_chans, int embed_dim);
 /* dst[i] = bf16(src[i]), round to nearest even; count % 4 == 0. */
 int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short *dst, size_t count);
 

@@ -87,14 +87,15 @@ def test_gemm_bf16_persistent_many_tiles(variant, epi, M, N, K):
     assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-5).all(), float(err.max())
 
 
+@pytest.mark.parametrize("implicit", [False, True], ids=["two-pass", "implicit-gemm"])
 @pytest.mark.parametrize("cfg,n", [(synth.VIT_B16, 3), (synth.VIT_SMALL, 5)])
-def test_patch_embed_bf16(oracle, cfg, n):
+def test_patch_embed_bf16(oracle, cfg, n, implicit):
     """Patch embedding on the bf16 pipe vs the oracle's conv/flatten/class-token/pos_emb on the SAME bf16-rounded
     pixels and conv weights: only the fp32 accumulation order differs."""
     from conftest import oracle_config
     W = [synth.make_weight(cfg, i, 5) for i in range(4)]
     imgs = synth.make_images(cfg, n, 6)
-    got = B.patch_embed_bf16(cfg, imgs, W[1], W[2], W[0], W[3])
+    got = B.patch_embed_bf16(cfg, imgs, W[1], W[2], W[0], W[3], implicit=implicit)
     Wr = list(W)
     Wr[1] = B.from_bf16_bits(B.to_bf16_bits(W[1])).reshape(W[1].shape)
     imgs_r = B.from_bf16_bits(B.to_bf16_bits(imgs)).reshape(imgs.shape)

@@ -334,11 +334,20 @@ def patch_embed(cfg: ModelConfig, images, conv_w, conv_b, cls, pos) -> np.ndarra
     return dx.numpy().reshape(n, cfg.tokens, cfg.embed_dim)
 
 
-def patch_embed_bf16(cfg: ModelConfig, images, conv_w, conv_b, cls, pos) -> np.ndarray:
-    """vithip_patch_embed_bf16: conv weight given in fp32 and rounded to bf16 here (as the engine does on upload)."""
+def patch_embed_bf16(cfg: ModelConfig, images, conv_w, conv_b, cls, pos, implicit: bool = False) -> np.ndarray:
+    """vithip_patch_embed_bf16 (two passes) or vithip_patch_embed_bf16_implicit (one implicit GEMM over the NCHW pixels):
+    conv weight given in fp32 and rounded to bf16 here (as the engine does on upload)."""
     images = _as_f32(images)
     n = images.shape[0]
     L = lib()
+    if implicit:
+        L.vithip_patch_embed_bf16_implicit.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5
+        d = [DeviceArray.from_numpy(_as_f32(a)) for a in (images, conv_b, cls, pos)]
+        dw = DeviceArray.from_numpy(to_bf16_bits(_as_f32(conv_w).reshape(cfg.embed_dim, -1)))
+        dx = DeviceArray((n * cfg.tokens, cfg.embed_dim))
+        hip_check(L.vithip_patch_embed_bf16_implicit(None, d[0].ptr, dw.ptr, d[1].ptr, d[2].ptr, d[3].ptr, dx.ptr, n, cfg.img_size,
+                                                     cfg.patch_size, cfg.in_chans, cfg.embed_dim), "vithip_patch_embed_bf16_implicit")
+        return dx.numpy().reshape(n, cfg.tokens, cfg.embed_dim)
     L.vithip_patch_embed_bf16.argtypes = [C.c_void_p] * 8 + [C.c_int] * 5
     d = [DeviceArray.from_numpy(_as_f32(a)) for a in (images, conv_b, cls, pos)]
     dw = DeviceArray.from_numpy(to_bf16_bits(_as_f32(conv_w).reshape(cfg.embed_dim, -1)))

@@ -394,6 +394,21 @@ int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const u
     return vitgemm::launch_gemm_bf16_pp(s, p, VITHIP_BF16_EPI_F32_EMBED, g_cus);
 }
 
+int vithip_patch_embed_bf16_implicit(vithip_stream_t stream, const float *images, const unsigned short *conv_w16, const float *conv_b,
+                                     const float *cls, const float *pos, float *x, int n_images, int img_size, int patch_size,
+                                     int in_chans, int embed_dim) {
+    if (!images || !conv_w16 || !conv_b || !cls || !pos || !x || n_images <= 0) return static_cast<int>(hipErrorInvalidValue);
+    if (patch_size <= 0 || patch_size % 4 || img_size % patch_size || img_size % 4 || in_chans <= 0 || embed_dim <= 0)
+        return static_cast<int>(hipErrorInvalidValue);
+    const int K = in_chans * patch_size * patch_size;
+    if (K % 32 || (long long)n_images * (img_size / patch_size) * (img_size / patch_size) > (1ll << 24) ||
+        (long long)n_images * in_chans * img_size * img_size >= (1ll << 32))
+        return static_cast<int>(hipErrorInvalidValue);
+    if (!aligned16(images) || !aligned16(conv_w16) || !aligned16(x)) return static_cast<int>(hipErrorInvalidValue);
+    return vitgemm::launch_patch_embed_bf16(static_cast<hipStream_t>(stream), images, conv_w16, conv_b, cls, pos, x, n_images, img_size,
+                                            patch_size, in_chans, embed_dim);
+}
+
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->K % TBK || a->N % 4) return static_cast<int>(hipErrorInvalidValue);

@@ -246,5 +246,9 @@ struct Bf16Params {
     int stagger;              // ping-pong kernel: start-up skew between workgroups, in units of 512 cycles
 };
 int launch_gemm_bf16_pp(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);
+// vit_patch_embed_bf16.hip: patch embedding on the bf16 pipe as one implicit GEMM over the NCHW fp32 images
+int launch_patch_embed_bf16(hipStream_t s, const float *images, const unsigned short *conv_w16, const float *conv_b,
+                            const float *cls, const float *pos, float *x, int n_images, int img_size, int patch_size,
+                            int in_chans, int embed_dim);
 
 }  // namespace vitgemm
