@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Time and stamp the streamed bf16 attention kernel at ViT-L/16-384 (probe build for the stamps). GPU box only."""
+import importlib, json, os, sys, ctypes as C
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+B = importlib.import_module("vision-transformer-opencl_amd.binding")
+from tools.gemm_probe import timed
+n, T, heads = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 577, 16
+D = heads * 64
+rng = np.random.default_rng(0)
+q = B.to_bf16_bits(rng.uniform(-1.5, 1.5, (n * T, 3 * D)).astype(np.float32))
+dq = B.DeviceArray.from_numpy(q)
+do = B.DeviceArray((n * T, D), np.uint16)
+L = B.lib()
+L.vithip_attention_bf16io.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+ms = [timed(lambda: B.hip_check(L.vithip_attention_bf16io(None, dq.ptr, do.ptr, n, T, heads)), reps=5, warm=2) for _ in range(3)]
+flop = 2.0 * n * 2 * heads * T * T * 64
+print(json.dumps({"attention_ms": [round(m, 4) for m in ms], "tflops": round(flop / (min(ms) * 1e-3) / 1e12, 1)}))
+if hasattr(L, "vithip_attention_set_debug_buffer"):
+    dbg = B.DeviceArray((256 * 8, 16), np.uint64)
+    L.vithip_attention_set_debug_buffer.argtypes = [C.c_void_p]
+    L.vithip_attention_set_debug_buffer(dbg.ptr)
+    for _ in range(2):
+        B.hip_check(L.vithip_attention_bf16io(None, dq.ptr, do.ptr, n, T, heads))
+    d = dbg.numpy().astype(np.int64).reshape(256, 8, 16)
+    L.vithip_attention_set_debug_buffer(None)
+    for w in (0, 3, 7):
+        seg = np.median(d[:, w, 1:13] - d[:, w, 0:12], axis=0).astype(int)
+        print(json.dumps({"wave": w, "segments(top-barrier, then per step: compute, barrier)": seg.tolist()}))

@@ -27,6 +27,7 @@
 namespace vitattn {
 #ifdef VIT_PROBES
 extern unsigned long long *g_res_dbg;
+extern unsigned long long *g_stream_dbg;
 extern int g_res_mode;
 #endif
 int attention_f32_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows);  // vit_attention_resident.hip
@@ -823,6 +824,7 @@ extern "C" int vithip_attention_set_probe_mode(int mode) {
 extern "C" int vithip_attention_set_debug_buffer(void *buf) {
     g_attn_dbg = static_cast<unsigned long long *>(buf);
     vitattn::g_res_dbg = g_attn_dbg;
+    vitattn::g_stream_dbg = g_attn_dbg;
     return 0;
 }
 #endif
@@ -880,9 +882,9 @@ static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv,
             case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads, q_rows);
             case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads, q_rows);
             default: {
-                // 225..768 tokens (ViT-L/16-384: 577): all query blocks of a head in one persistent workgroup, K/V streamed
+                // 225..704 tokens (ViT-L/16-384: 577): all query blocks of a head in one persistent workgroup, K/V streamed
                 // once through an LDS-DMA ring (vit_attention_stream.hip); longer sequences: the chunked kernel below
-                if (tokens <= 768) return vitattn::attention_bf16_stream(s, qkv, out, n_images, tokens, heads);
+                if (tokens <= 704) return vitattn::attention_bf16_stream(s, qkv, out, n_images, tokens, heads);
                 const int qblocks = ((tokens + 31) / 32 + ATT_WAVES - 1) / ATT_WAVES;
                 hipLaunchKernelGGL(attention_bf16_chunked_kernel, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s, qkv,
                                    out, tokens, heads);

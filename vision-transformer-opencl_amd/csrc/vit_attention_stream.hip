@@ -59,8 +59,22 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const bf16_t *Vs, int key16, int dt,
 }
 
 __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
-                                                                           int tokens, int heads, int n_items) {
-    __shared__ __attribute__((aligned(1024))) bf16_t lds[2 * SBUF];  // 2 x (16 KB + 16 KB)
+                                                                           int tokens, int heads, int n_items
+#ifdef VIT_PROBES
+                                                                           , unsigned long long *__restrict__ dbg
+#endif
+) {
+#ifdef VIT_PROBES
+    unsigned long long ts[16] = {};
+    int nts = 0, it_no = 0;
+#define ST_STAMP() do { if (dbg && it_no == 1 && nts < 16) ts[nts++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ST_STAMP() do { } while (0)
+#endif
+    // ring: 2 x (K 16 KB + V 16 KB); behind it the Q blocks of the head (32 rows x 128 B each, swizzled like K), indexed by
+    // block: a wave reads and refills only ITS blocks, so Q needs no barrier of its own
+    extern __shared__ __attribute__((aligned(1024))) bf16_t lds[];
+    bf16_t *const Qs = lds + 2 * SBUF;
 
     const int D = heads * SHD, ld = 3 * D;
     const int tid = threadIdx.x;
@@ -142,25 +156,39 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 
     // ---- this wave's query blocks: wave, wave + 8, wave + 16 ------------------------------------------------------
     const int nblk = nkt;  // 32-row query blocks = 32-key tiles
-    bf16x8 qf[MAXB][4];
     f32x16 o[MAXB][2];
     float m_run[MAXB], l_run[MAXB];
-    auto load_q = [&](int item) __attribute__((always_inline)) {
-        const bf16_t *base = item_base(item);
+    // Q blocks of this wave for `item` -> LDS (4 wave instructions of 8 rows per block); rows past the end are clamped
+    auto dma_q = [&](int item) __attribute__((always_inline)) {
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int row_l = lane_l >> 3, pos = lane_l & 7;
+        const int4v rq = make_rsrc4(item_base(item));
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
-            if (wave + ST_WAVES * b < nblk) {
-                int qrow = (wave + ST_WAVES * b) * 32 + r;
-                qrow = qrow < tokens ? qrow : tokens - 1;
-                const bf16_t *qsrc = base + (size_t)qrow * ld + h * 8;
+            const int blk = wave + ST_WAVES * b;
+            if (blk < nblk) {  // wave-uniform
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *reinterpret_cast<const bf16x8 *>(qsrc + ks * 16);
+                for (int t = 0; t < 4; ++t) {
+                    const int lrow = 8 * t + row_l;
+                    int srow = blk * 32 + lrow;
+                    srow = srow < tk ? srow : tk - 1;
+                    dma16(rq, Qs + blk * (32 * SHD) + t * 512, srow * ld * 2 + ((pos ^ ((lrow >> 1) & 7)) << 4), 0);
+                }
             }
         }
     };
 
     // One step = one chunk of one item, reading ring slot `slot` while the DMA of the following step fills the other one.
+    //
+    // Inside a step a wave walks its (block, 64-key sub-chunk) units.  The kernel is bound by the softmax's VALU work, not
+    // by the matrix pipe (per unit 16 MFMAs = 512 cycles against 32 v_exp_f32 at quarter rate plus scale / sum / max /
+    // bf16 packing), and a unit is a dependent chain S -> softmax -> PV: run one after the other the two never overlapped
+    // (1,900 cycles per unit measured).  So the units are software-pipelined -- the score MFMAs of the NEXT unit are issued
+    // before the softmax of the current one, two score buffers alternate -- and the element-wise work is written on float
+    // pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two values per instruction).
     const int sw = (r >> 1) & 7, h4 = 4 * h;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto step = [&](int slot, int item, int ch, int next_item, int next_ch) __attribute__((always_inline)) {
         asm volatile("" : "+s"(tk));
         if (next_item >= 0) dma_chunk(next_item, next_ch, slot ^ 1);
@@ -168,79 +196,116 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
         const int key_base = chunk_first(ch) * 32;
         int valid = chunk_tiles(ch) * 32;                      // keys of this chunk ...
         valid = tk - key_base < valid ? tk - key_base : valid;  // ... that exist
+        const bool two = SUB * 32 < valid;                      // wave-uniform: the chunk has a second sub-chunk
+
+        f32x16 st[2][SUB];  // two score buffers
+        // scores of sub-chunk k0 of block b -> buffer `buf`.  A sub-chunk is always computed whole: keys past `valid` (a
+        // chunk of 3 tiles, the end of the sequence) hold older, finite data in LDS and are masked to -inf below.
+        auto scores = [&](int buf, int b, int k0) __attribute__((always_inline)) {
+            const bf16_t *qrow = Qs + (wave + ST_WAVES * b) * (32 * SHD) + r * SHD;
+            bf16x8 qf[4];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            if (wave + ST_WAVES * b >= nblk) continue;  // wave-uniform
-            // The chunk is taken in sub-chunks of SUB key tiles (scores of 64 keys in registers at a time: three blocks of
-            // O^T accumulators plus their Q fragments leave room for no more); each runs one online-softmax update.
-            // A sub-chunk is always computed whole: keys past `valid` (a chunk of 3 tiles, the end of the sequence) hold
-            // older, finite data in LDS and are masked to -inf, i.e. weigh exactly 0.
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qrow + (((2 * ks + h) ^ sw) & 7) * 8);
 #pragma unroll
-            for (int k0 = 0; k0 < SKT; k0 += SUB) {
-                if (k0 * 32 >= valid) continue;  // wave-uniform
-                f32x16 st[SUB];
+            for (int u = 0; u < SUB; ++u)
 #pragma unroll
-                for (int u = 0; u < SUB; ++u) {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) st[u][v] = 0.0f;
-                    const bf16_t *krow = Ks + ((k0 + u) * 32 + r) * SHD;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + h) ^ sw) & 7) * 8);
-                        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ks], st[u], 0, 0, 0);
-                    }
-                }
-                if ((k0 + SUB) * 32 > valid) {  // wave-uniform: the sub-chunk reaches past the valid keys
-#pragma unroll
-                    for (int u = 0; u < SUB; ++u)
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) {
-                            const int kloc = (k0 + u) * 32 + (v & 3) + 8 * (v >> 2) + h4;
-                            st[u][v] = kloc < valid ? st[u][v] : -INFINITY;
-                        }
-                }
-                // ---- online softmax: running max m, running sum l, O rescaled by 2^((m_old - m_new) c) when m moved
-                float cmax = -INFINITY;
+                for (int v = 0; v < 16; ++v) st[buf][u][v] = 0.0f;
+            // K fragments are read one k-step AHEAD of the MFMAs that use them (two register sets): left to itself hipcc issues
+            // read - wait - MFMA for every instruction, i.e. every MFMA pays an LDS round trip
+            bf16x8 kf[2][SUB];
+            auto read_k = [&](int ks, int set) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < SUB; ++u)
+                    kf[set][u] = *reinterpret_cast<const bf16x8 *>(Ks + ((k0 + u) * 32 + r) * SHD + (((2 * ks + h) ^ sw) & 7) * 8);
+            };
+            read_k(0, 0);
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, st[u][v]);
-                cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-                const float m_old = m_run[b];
-                const float m_new = fmaxf(m_old, cmax);  // finite: the sub-chunk has at least one valid key
-                m_run[b] = m_new;
-                const float mxs = -m_new * kScaleS;
-                float csum = 0.0f;
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) read_k(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < SUB; ++u)  // the SUB tiles are independent accumulation chains
+                    st[buf][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][u], qf[ks], st[buf][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // online softmax of buffer `buf` (running max m, running sum l, O rescaled by 2^((m_old - m_new) c) when m moved),
+        // then O^T += V^T . P^T
+        auto softmax_pv = [&](int buf, int b, int k0) __attribute__((always_inline)) {
+            if ((k0 + SUB) * 32 > valid) {  // wave-uniform: the sub-chunk reaches past the valid keys
 #pragma unroll
                 for (int u = 0; u < SUB; ++u)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(st[u][v], kScaleS, mxs));  // exp2(-inf) = 0: masked keys
-                        st[u][v] = e;
-                        csum += e;
-                    }
-                if (__any(m_new != m_old)) {  // wave-uniform: most sub-chunks leave every row's maximum where it was
-                    const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * kScaleS);  // first one: exp2(-inf) = 0
-                    l_run[b] *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) o[b][dt][v] *= alpha;
-                }
-                l_run[b] += csum;
-                // ---- O^T += V^T . P^T
-#pragma unroll
-                for (int u = 0; u < SUB; ++u)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        bf16x8 pf;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[u][8 * s2 + j];
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-                            o[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag_tr(Vs, (k0 + u) * 32 + 16 * s2, dt, lane), pf, o[b][dt], 0, 0, 0);
+                        const int kloc = (k0 + u) * 32 + (v & 3) + 8 * (v >> 2) + h4;
+                        st[buf][u][v] = kloc < valid ? st[buf][u][v] : -INFINITY;
                     }
             }
+            f32x2 mx2 = {-INFINITY, -INFINITY};
+#pragma unroll
+            for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                for (int v = 0; v < 16; v += 2) mx2 = __builtin_elementwise_max(mx2, f32x2{st[buf][u][v], st[buf][u][v + 1]});
+            float cmax = fmaxf(mx2[0], mx2[1]);
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float m_old = m_run[b];
+            const float m_new = fmaxf(m_old, cmax);  // finite: the sub-chunk has at least one valid key
+            m_run[b] = m_new;
+            const f32x2 sc2 = {kScaleS, kScaleS}, mxs2 = {-m_new * kScaleS, -m_new * kScaleS};
+            f32x2 sum2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                for (int v = 0; v < 16; v += 2) {
+                    const f32x2 t = __builtin_elementwise_fma(f32x2{st[buf][u][v], st[buf][u][v + 1]}, sc2, mxs2);
+                    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};  // exp2(-inf) = 0: masked keys
+                    st[buf][u][v] = e[0];
+                    st[buf][u][v + 1] = e[1];
+                    sum2 += e;
+                }
+            if (__any(m_new != m_old)) {  // wave-uniform: most sub-chunks leave every row's maximum where it was
+                const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * kScaleS);  // first one: exp2(-inf) = 0
+                l_run[b] *= alpha;
+                const f32x2 a2 = {alpha, alpha};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int v = 0; v < 16; v += 2) {
+                        const f32x2 w = f32x2{o[b][dt][v], o[b][dt][v + 1]} * a2;
+                        o[b][dt][v] = w[0];
+                        o[b][dt][v + 1] = w[1];
+                    }
+            }
+            l_run[b] += sum2[0] + sum2[1];
+            // P.V: the V^T fragments of 16-key group g+1 are read before the MFMAs of group g
+            bf16x8 vf[2][2];
+            auto read_v = [&](int g, int set) __attribute__((always_inline)) {  // g = 2 u + s2
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) vf[set][dt] = v_frag_tr(Vs, (k0 + (g >> 1)) * 32 + 16 * (g & 1), dt, lane);
+            };
+            read_v(0, 0);
+#pragma unroll
+            for (int g = 0; g < 2 * SUB; ++g) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[buf][g >> 1][8 * (g & 1) + j];
+                if (g + 1 < 2 * SUB) read_v(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g & 1][dt], pf, o[b][dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // pipeline over this wave's blocks (wave, wave + 8, wave + 16: contiguous in b)
+        if (wave < nblk) scores(0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            if (wave + ST_WAVES * b >= nblk) continue;  // wave-uniform
+            if (two) scores(1, b, SUB);                 // in the matrix pipe while the softmax below runs on the VALU
+            softmax_pv(0, b, 0);
+            if (b + 1 < MAXB && wave + ST_WAVES * (b + 1) < nblk) scores(0, b + 1, 0);  // the next block's first scores
+            if (two) softmax_pv(1, b, SUB);
         }
     };
     auto finish_item = [&](int item) __attribute__((always_inline)) {  // normalise and store this wave's blocks
@@ -273,8 +338,8 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     dma_chunk(item, 0, 0);
     int slot = 0;
 
+    dma_q(item);
     for (;;) {  // items
-        load_q(item);
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
             m_run[b] = -INFINITY;
@@ -284,25 +349,47 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 #pragma unroll
                 for (int v = 0; v < 16; ++v) o[b][dt][v] = 0.0f;
         }
-        // Q (ordinary loads) and the chunk that is about to be read (LDS-DMA) are both complete after this barrier
+        // this head's Q blocks and the chunk that is about to be read (all LDS-DMA) have landed after this barrier
+        ST_STAMP();
         ring_barrier();
+        ST_STAMP();
         const int next_item = item + stride;
         for (int ch = 0; ch < nch; ++ch) {
             // the step after this one: the next chunk of this head, or the first chunk of the next head
             const int ni = ch + 1 < nch ? item : (next_item < n_items ? next_item : -1);
             const int nc = ch + 1 < nch ? ch + 1 : 0;
             step(slot, item, ch, ni, nc);
-            if (ch == nch - 1) finish_item(item);
+            ST_STAMP();
+            if (ch == nch - 1) {
+                finish_item(item);
+                if (next_item < n_items) dma_q(next_item);  // this wave is done with its Q blocks: refill them for the next head
+            }
             slot ^= 1;
             if (ch + 1 < nch) ring_barrier();  // the next chunk has landed, everybody is done with this one
+            ST_STAMP();
             // (after the last chunk the barrier is the one at the top of the next item, behind its Q loads)
         }
         if (next_item >= n_items) break;
         item = next_item;
+#ifdef VIT_PROBES
+        ++it_no;
+#endif
     }
+#ifdef VIT_PROBES
+    if (dbg && lane == 0) {
+        unsigned long long *d = dbg + ((size_t)blockIdx.x * ST_WAVES + wave) * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = ts[k];
+    }
+#endif
+#undef ST_STAMP
 }
 
-// 224 < tokens <= 768.  Returns a hipError_t value.
+#ifdef VIT_PROBES
+unsigned long long *g_stream_dbg = nullptr;
+#endif
+
+// 224 < tokens <= 704 (the head's Q blocks share the LDS with the K/V ring).  Returns a hipError_t value.
 int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads) {
     static int cus = 0;
     if (cus == 0) {
@@ -311,10 +398,23 @@ int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned sho
             return static_cast<int>(hipErrorInvalidDevice);
         cus = v;
     }
-    if (tokens > ST_WAVES * MAXB * 32) return static_cast<int>(hipErrorInvalidValue);
+    const int nblk = (tokens + 31) / 32;
+    const size_t lds_bytes = (size_t)(2 * SBUF + nblk * 32 * SHD) * sizeof(bf16_t);  // ring + the head's Q blocks
+    if (tokens > ST_WAVES * MAXB * 32 || lds_bytes > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bf16_stream_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return static_cast<int>(e);
+        attr_set = true;
+    }
     const int items = n_images * heads;
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL(attention_bf16_stream_kernel, dim3(grid), dim3(ST_THREADS), 0, s, qkv, out, tokens, heads, items);
+#ifdef VIT_PROBES
+    hipLaunchKernelGGL(attention_bf16_stream_kernel, dim3(grid), dim3(ST_THREADS), lds_bytes, s, qkv, out, tokens, heads, items, g_stream_dbg);
+#else
+    hipLaunchKernelGGL(attention_bf16_stream_kernel, dim3(grid), dim3(ST_THREADS), lds_bytes, s, qkv, out, tokens, heads, items);
+#endif
     return static_cast<int>(hipGetLastError());
 }
 
