@@ -147,3 +147,25 @@ def test_bench_rank_takes_the_rccl_path_at_world_size_one():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["top1_gather"] == "rccl all_gather, 8 B per image"
     assert rec["value"] > 0
+
+
+@pytest.mark.parametrize("n_images", [6, 5])
+def test_two_ranks_shard_the_batch_over_hip_engines(small, n_images):
+    """The data-parallel path with the HIP engine as each rank's forward: two rank processes (started by the launcher
+    bench.py uses) forward their contiguous shard on their own engine, all-gather the top-1 records, and rank 0 holds the
+    whole batch's labels / probabilities -- equal to one engine forwarding everything."""
+    import io
+    import importlib
+    pkg = importlib.import_module("vision-transformer-opencl_amd")
+    worker = os.path.join(ROOT, "tests", "workers", "dp_gpu_worker.py")
+    rc, out = pkg.launch.launch_ranks(worker, [str(n_images)], 2, timeout=600, relay_stdout=io.StringIO())
+    assert rc == 0
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    cfg, W, _ = small
+    eng = B.Engine(cfg, max_batch=8)
+    eng.load_weights(W)
+    full = eng.forward(synth.make_images(cfg, n_images, 8))
+    eng.close()
+    assert rec["world"] == 2 and rec["n_local"] == pkg.dp.shard_range(n_images, 0, 2)[1]
+    assert rec["labels"] == full.argmax(1).tolist()
+    assert np.array_equal(np.asarray(rec["probs"], np.float32), full.max(1))
