@@ -31,10 +31,10 @@ sys.path.insert(0, ROOT)
 METRIC = "images/sec ViT-B/16 224² fp32 @batch256; % MFMA roofline; top-1 match"
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA (16x the fp32 matrix rate), no sparsity
-STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it
+STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it at the metric configuration (fp32, batch 256, one lane)
     "qkv": "gemm_f32_nt_persistent_kernel<EPI_BIAS>", "head": "gemm_f32_nt_persistent_kernel<EPI_BIAS>",
     "fc1": "gemm_f32_nt_persistent_kernel<EPI_BIAS_GELU>",
-    "outproj": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>",
+    "outproj": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_persistent_kernel<EPI_BIAS_RESIDUAL>",
     "attn": "attention_f32_resident_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
     "softmax": "softmax_top1_f32_kernel",
 }
@@ -114,7 +114,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-forward-per-core aggregate CPU figure")
     ap.add_argument("--cpu-all-cores", type=int, default=16,
                     help="cap on concurrent single-threaded CPU forwards for cpu_baseline.all_cores (a 1-GPU box's CPU share is 16)")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=1,
                     help="concurrent sub-batches per step (engine option; 1 = every kernel alone on the GPU)")
     ap.add_argument("--kernel-steps", type=int, default=3,
                     help="extra steps with lanes=1 and per-launch event brackets for the roofline object (when lanes > 1)")
@@ -126,9 +126,12 @@ def main() -> None:
                     help="NOT the metric configuration: vit_engine_options.prune_last_layer (the last encoder layer computes "
                          "only the class rows; bit-identical probabilities, 7 %% less arithmetic).  FLOP figures then count "
                          "the executed work")
-    ap.add_argument("--no-stage-brackets", action="store_true",
-                    help="with --lanes 1: keep the per-launch event brackets out of the timed steps (they cost ~0.5 ms per "
-                         "forward at batch 1); the roofline pass then runs afterwards, as with lanes > 1")
+    ap.add_argument("--stage-brackets", dest="no_stage_brackets", action="store_false",
+                    help="with --lanes 1: record the per-launch event brackets INSIDE the timed steps (they cost ~0.5 ms per "
+                         "forward at batch 1, 1-3 %% at batch 256); default: the timed steps carry no instrumentation and the "
+                         "roofline pass (same batch, same kernels, every launch bracketed) runs right after them")
+    ap.add_argument("--no-stage-brackets", dest="no_stage_brackets", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(no_stage_brackets=True)
     ap.add_argument("--graph", action="store_true",
                     help="vit_engine_options.use_graph: replay the forward as one hipGraph (needs --lanes 1; small batches)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
@@ -296,8 +299,9 @@ def main() -> None:
         "whole_model_frac": round(model_tflops / peak, 4),
         "stage_ms_per_step": {s: round(r["ms"] / kernel_steps, 3) for s, r in times["stages"].items()},
         "measured": ("HIP events around every launch during the timed steps" if (args.lanes == 1 and not args.graph and not args.no_stage_brackets) else
-                     f"HIP events around every launch in {kernel_steps} extra steps with lanes=1 after the timed region "
-                     f"(the timed steps run {args.lanes} concurrent lanes, whose kernels overlap)"),
+                     f"HIP events around every launch in {kernel_steps} extra steps with lanes=1 right after the timed region "
+                     + (f"(the timed steps run {args.lanes} concurrent lanes, whose kernels overlap)" if args.lanes > 1 else
+                        "(same batch, same kernels; the timed steps themselves carry no instrumentation)")),
     }
 
     # ---- CPU baseline + parity on the sampled image (rank 0, N = 1 only) -------------------------

@@ -101,8 +101,16 @@ typedef struct {
      *   8 = 128x64, 11 = 64x64 (auto for problems that leave CUs idle); 9 = persistent 128x128.
      * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default 8; 1 = plain N-fastest order). */
     int tile, group_m;
+    /* optional scratch made by vithip_gemm_f32_workspace_create() (uncached device memory, flags zeroed) and then left to the
+     * library (one per stream: launches that share it must be ordered).  With it, large problems whose tile count is not a multiple of the
+     * workgroup count hand the first K-steps of the last round's tiles to the workgroups that would idle (bit-identical
+     * results: the accumulation chain moves between workgroups, it is not split; csrc/vit_gemm_persistent.hip).  NULL = off. */
+    void *workspace;
 } vithip_gemm_args;
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
+size_t vithip_gemm_f32_workspace_bytes(void);
+int vithip_gemm_f32_workspace_create(void **workspace);   /* on the current device */
+int vithip_gemm_f32_workspace_destroy(void *workspace);
 /* ---- bf16 variant (BASELINE.json configs[2]) ---------------------------------
  * bf16 values are raw uint16 (upper half of the fp32 bit pattern, round-to-nearest-even). */
 enum { VITHIP_BF16_EPI_BF16 = 0, VITHIP_BF16_EPI_BF16_GELU = 1, VITHIP_BF16_EPI_F32_RESIDUAL = 2,

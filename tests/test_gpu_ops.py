@@ -83,6 +83,32 @@ def test_gemm_tile_shapes_are_bit_identical():
         assert np.array_equal(B.gemm(A[:7], W, b, residual=None if res is None else res[:7], epilogue=epi), ref[:7]), epi
 
 
+def test_gemm_helper_pieces_are_bit_identical_and_reusable():
+    """Persistent walk with a workspace: the tiles of the partial last round start on an idle workgroup and finish on their
+    owner (csrc/vit_gemm_persistent.hip).  600 tiles on 512 workgroups: 88 owners hand 12 of 24 K-steps to a helper.  The
+    accumulation chain moves, it is not split: results must equal the one-workgroup-per-tile kernel bit for bit, for every
+    epilogue, and again when the same workspace serves the next launch (the owner resets its flag)."""
+    import ctypes as C
+    M, N, K = 128 * 100, 768, 768
+    A, W, b, R = u(50, (M, K), 1.0), u(51, (N, K), 0.05), u(52, (N,), 0.1), u(53, (M, N), 2.0)
+    L = B.lib()
+    ws = B.gemm_workspace()
+    dA, dW, db, dR = (B.DeviceArray.from_numpy(a) for a in (A, W, b, R))
+    for epi, res in ((B.EPI_BIAS, None), (B.EPI_BIAS_GELU, None), (B.EPI_BIAS_RESIDUAL, R)):
+        ref = B.gemm(A, W, b, residual=res, epilogue=epi, tile=1)
+        for rep in range(2):
+            dC = B.DeviceArray.from_numpy(np.full((M, N), 7.0, np.float32))
+            args = B.CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if res is not None else None, N, dC.ptr, N, M, N, K, epi, 9, 0, ws)
+            B.hip_check(L.vithip_gemm_f32(None, C.byref(args)), "vithip_gemm_f32")
+            assert np.array_equal(dC.numpy(), ref), (epi, rep)
+    flags = np.empty(1024, np.int32)
+    B.hip_check(L.vithip_device_sync(), "sync")
+    B.hip_check(L.vithip_memcpy_d2h(flags.ctypes.data, ws, flags.nbytes, None), "d2h")
+    B.hip_check(L.vithip_device_sync(), "sync")
+    assert not flags.any()                                                     # every flag is back to "empty"
+    L.vithip_gemm_f32_workspace_destroy(C.c_void_p(ws))
+
+
 def test_gemm_rejects_bad_k():
     A, W, b = u(15, (8, 40), 1.0), u(16, (8, 40), 1.0), u(17, (8,), 1.0)
     with pytest.raises(B.VitError):

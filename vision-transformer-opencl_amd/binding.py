@@ -65,7 +65,7 @@ class CGemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("epilogue", C.c_int), ("tile", C.c_int), ("group_m", C.c_int)]
+                ("epilogue", C.c_int), ("tile", C.c_int), ("group_m", C.c_int), ("workspace", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -204,17 +204,29 @@ class DeviceArray:
             pass
 
 
-def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: int = 0) -> np.ndarray:
-    """C = epilogue(A . W^T + bias) through vithip_gemm_f32 (tile / group_m: per-call tuning fields, 0 = auto)."""
+def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: int = 0, workspace: bool = False) -> np.ndarray:
+    """C = epilogue(A . W^T + bias) through vithip_gemm_f32 (tile / group_m: per-call tuning fields, 0 = auto;
+    workspace: lend the scratch that enables the helper pieces of the persistent walk)."""
     A, W, bias = _as_f32(A), _as_f32(W), _as_f32(bias)
     M, K = A.shape
     N = W.shape[0]
     dA, dW, db = DeviceArray.from_numpy(A), DeviceArray.from_numpy(W), DeviceArray.from_numpy(bias)
     dC = DeviceArray((M, N))
     dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
-    args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue, tile, group_m)
+    ws = gemm_workspace() if workspace else None
+    args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue, tile, group_m, ws)
     hip_check(lib().vithip_gemm_f32(None, C.byref(args)), "vithip_gemm_f32")
-    return dC.numpy()
+    out = dC.numpy()
+    if ws:
+        lib().vithip_gemm_f32_workspace_destroy(C.c_void_p(ws))
+    return out
+
+
+def gemm_workspace() -> int:
+    """vithip_gemm_f32_workspace_create: the scratch of vithip_gemm_args.workspace (free with vithip_gemm_f32_workspace_destroy)."""
+    p = C.c_void_p()
+    hip_check(lib().vithip_gemm_f32_workspace_create(C.byref(p)), "vithip_gemm_f32_workspace_create")
+    return p.value
 
 
 class CGemmBf16Args(C.Structure):

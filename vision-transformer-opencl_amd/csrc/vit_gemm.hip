@@ -35,6 +35,7 @@
 namespace vitgemm {
 int launch_persistent(hipStream_t stream, GemmParams &p, int epilogue, int group_m);  // vit_gemm_persistent.hip
 int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, int group_m);
+int persistent_piece_steps(int M, int N, int K);
 }
 
 namespace {
@@ -402,6 +403,10 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
                 return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);
             if (epilogue == VITHIP_EPI_BIAS_RESIDUAL) {
                 if (tiles < 1024) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
+                // with a workspace the persistent walk hands the first K-steps of the partial last round's tiles to idle
+                // workgroups (fc2 / out_proj at batch 256: 480 -> 448 steps per workgroup); without one the residual
+                // epilogue is marginally faster one tile per workgroup (fc2 21.30 vs 21.43 ms per step)
+                if (p.sk_ws && vitgemm::persistent_piece_steps(p.M, p.N, p.K) > 0) return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
                 return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
             }
             if (tiles < 2048) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
@@ -437,6 +442,22 @@ int vithip_gemm_set_group(int group_m) {
 }
 #endif
 
+size_t vithip_gemm_f32_workspace_bytes(void) { return 4096 + (size_t)1024 * 128 * 128 * 4; }  // flags + one slot per workgroup (<= 2 x 512 CUs)
+
+// The scratch of vithip_gemm_args.workspace: uncached device memory (accesses bypass the per-XCD L2s, so the workgroup that
+// parks accumulators and the one that picks them up need no cache maintenance), flags zeroed.
+int vithip_gemm_f32_workspace_create(void **ws) {
+    if (!ws) return static_cast<int>(hipErrorInvalidValue);
+    *ws = nullptr;
+    hipError_t e = hipExtMallocWithFlags(ws, vithip_gemm_f32_workspace_bytes(), hipDeviceMallocUncached);
+    if (e != hipSuccess) return static_cast<int>(e);
+    e = hipMemset(*ws, 0, 4096);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(*ws); *ws = nullptr; }
+    return static_cast<int>(e);
+}
+int vithip_gemm_f32_workspace_destroy(void *ws) { return ws ? static_cast<int>(hipFree(ws)) : 0; }
+
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->K % KALIGN != 0) return static_cast<int>(hipErrorInvalidValue);
@@ -451,6 +472,8 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.R = a->residual; p.C = a->C;
     p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
     p.M = a->M; p.N = a->N; p.K = a->K;
+    p.sk_ws = a->workspace;
+    if (a->workspace && (reinterpret_cast<size_t>(a->workspace) & 15)) return static_cast<int>(hipErrorInvalidValue);
     if (a->tile < 0 || a->tile > 11 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
     return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue, a->tile, a->group_m);
 }

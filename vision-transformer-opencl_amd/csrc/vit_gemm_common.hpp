@@ -34,6 +34,9 @@ struct GemmParams {
     int patch;       // P
     int img;         // S
     int chans;       // C
+    // persistent kernel, helper pieces (vit_gemm_persistent.hip): workspace lent by the caller (NULL: off), piece length
+    void *sk_ws;
+    int sk_x;
 };
 
 // erf(x) = sign(x) * (1 - exp(t*q(t))), t = min(|x|, 4), q = degree-7 minimax fit of log(erfc(t))/t

@@ -14,6 +14,19 @@
 // 1 M partner-wave v_fma add 2.4 M cycles to an MFMA-bound loop), so every VALU instruction in the
 // loop or the epilogue is paid for in matrix throughput; the bookkeeping below is scalar (SALU)
 // wherever it is wave-uniform.
+//
+// Tile quantisation and the helper pieces (round 2).  fc2 / out_proj at batch 256 are 394 x 6 = 2,364 tiles on 512 workgroups:
+// 4.62 rounds paid as 5 -- 316 workgroups own five tiles, 196 four, and for the length of one tile 38 % of the chip idles
+// (7.7 % of the kernel; the stage model 0.923 x 0.95 matched the measured 0.877 of the clock-limited peak).  The owners of a
+// fifth tile now hand the FIRST x K-steps of it to a four-tile workgroup: the helper runs that piece before its own tiles,
+// parks the 64 KB of accumulators in a workspace slot and raises the slot's flag; the owner, at the very end of its walk, loads
+// them as its INITIAL accumulators and continues with K-steps x..nk.  Every output still sums its k in the sequential order with
+// the same instruction -- the hand-over moves an accumulation chain between workgroups, it does not split it -- so the result is
+// bit-identical to the one-workgroup tile (tests/test_gpu_ops.py::test_gemm_tile_shapes_are_bit_identical), which plain
+// split-K / stream-K fix-ups are not.  With c = ceil(owners / helpers) pieces per helper and x = floor(nk / (c + 1)) every workgroup
+// ends within full x nk + c x steps: fc2 448 instead of 480 (ideal 443.25), out_proj 112 / 120, fc1 444 / 456.
+// Dependencies: a helper waits for nobody; an owner waits, after all its own tiles, for a piece its helper finished first thing.
+// The wait is bounded (it gives up after ~60 ms and the result is wrong, not hung).
 #include "vit_gemm_common.hpp"
 
 namespace vitgemm {
@@ -21,7 +34,8 @@ namespace vitgemm {
 constexpr int PBK = 32;           // K step
 constexpr int PLD = PBK + 4;      // padded LDS row (floats)
 
-template <int BM, int BN, int WM, int WN, int EPI, bool STAMP = false>
+// SK: helper pieces compiled in (launches without them use the SK = false instantiation: no segment bookkeeping in its registers)
+template <int BM, int BN, int WM, int WN, int EPI, bool STAMP = false, bool SK = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const GemmParams p) {
     constexpr int ROWS_PER_PASS = 256 / (PBK / 4);
     constexpr int WGN = BN / WN;
@@ -52,8 +66,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     const int nwg = gridDim.x;
     const int first = xcd_remap(blockIdx.x, nwg);  // XCD-mates take neighbouring tiles of every round
     if (first >= total) return;                    // workgroup-uniform
-    const int my_tiles = (total - first + nwg - 1) / nwg;
     const int nk = p.K / PBK;
+
+    // ---- this workgroup's walk: segments (tile, k0, k1, partial in, partial out), all wave-uniform ----------------------
+    //   helper (first >= R, pieces on):  its pieces [0, x) of the owners' extra tiles, then `full` whole tiles
+    //   owner  (first <  R):             `full` whole tiles, then its extra tile: [x, nk) from the parked partial, or [0, nk)
+    const int full = total / nwg, R = total - full * nwg;
+    const int x = SK ? p.sk_x : 0;               // K-steps of an extra tile that its helper runs (0: no pieces)
+    const int H = nwg - R;
+    const bool owner = first < R;
+    const int npre = (x > 0 && !owner && R > 0) ? (R - (first - R) + H - 1) / H : 0;  // owners first-R, first-R+H, ...
+    const int nseg = npre + full + (owner ? 1 : 0);
+    struct Seg { int tile, k0, k1, in, out; };
+    auto get_seg = [&](int i) -> Seg {
+        Seg g;
+        if (i < npre) {
+            const int o = (first - R) + i * H;
+            g.tile = full * nwg + o; g.k0 = 0; g.k1 = x; g.in = -1; g.out = o;
+        } else if (i < npre + full) {
+            g.tile = first + (i - npre) * nwg; g.k0 = 0; g.k1 = nk; g.in = -1; g.out = -1;
+        } else {
+            g.tile = first + full * nwg; g.k0 = x; g.k1 = nk; g.in = x > 0 ? first : -1; g.out = -1;
+        }
+        return g;
+    };
 
     const int ld_row = tid / (PBK / 4);
     const int ld_kc = (tid % (PBK / 4)) * 4;
@@ -91,15 +127,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         }
     };
 
-    // ---- load cursor: the (tile, k-step) the NEXT staging load will fetch ----------------------
-    int tile_l = first, k_l = 0;
-    set_sources(tile_l);
+    // ---- load cursor: the (segment, k-step) the NEXT staging load will fetch ----------------------
+    int seg_l = 0, k_l, kend_l;
+    {
+        const Seg g = get_seg(0);
+        set_sources(g.tile);
+        k_l = g.k0;
+        kend_l = g.k1;
+    }
     auto advance_load_cursor = [&]() {
-        if (++k_l == nk) {
-            k_l = 0;
-            tile_l += nwg;
-            // past the last tile the old sources stay: harmless re-reads into a buffer nobody uses
-            if (tile_l < total) set_sources(tile_l);
+        if (++k_l == kend_l) {
+            // past the last segment the old sources stay: harmless re-reads into a buffer nobody uses
+            if (++seg_l < nseg) {
+                const Seg g = get_seg(seg_l);
+                set_sources(g.tile);
+                k_l = g.k0;
+                kend_l = g.k1;
+            } else {
+                k_l = kend_l - 1;
+            }
         }
     };
     auto load_step = [&]() {
@@ -144,24 +190,80 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * PLD);
     };
 
+    // ---- parked accumulators: slot o = 64 KB, float4 q of thread t at ((q * 256 + t) * 16) bytes; flag o: 0 empty, 1 ready ----
+    f32x16 acc[TM][TN];
+    int *const sk_flags = reinterpret_cast<int *>(p.sk_ws);
+    auto slot_ptr = [&](int o) { return reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.sk_ws) + 4096 + (size_t)o * (BM * BN * 4)); };
+    auto park = [&](int o) {  // helper: accumulators -> slot o, then the flag (release: the owner may sit on another XCD)
+        f32x4 *dst = slot_ptr(o) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
+                    dst[((i * TN + j) * 4 + q4) * 256] = v;
+                }
+        // The workspace is UNCACHED device memory (vithip_gemm_f32_workspace_create): stores go to memory, loads come from
+        // it, whichever XCD either side runs on.  So no agent-scope fences here: a release / acquire at agent scope writes
+        // back / invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1), which threw the A and W panels of the 63
+        // other workgroups of the XCD out with it (out_proj +22 % with them).  All that is needed is that every thread's
+        // stores have completed before the flag goes up: vmcnt(0), then the workgroup barrier.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sk_flags + o, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto unpark = [&](int o) {  // owner: wait for the piece (bounded), take it as the initial accumulators, free the slot
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(sk_flags + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 18))
+                __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();  // (uncached memory: nothing stale to drop, see park())
+        const f32x4 *src = slot_ptr(o) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 v = src[((i * TN + j) * 4 + q4) * 256];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q4 + e] = v[e];
+                }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sk_flags + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+    };
+
     // ---- compute cursor --------------------------------------------------------------------------
-    int tile_c = first, k_c = 0, m0, n0;
-    {
+    int seg_c = 0, k_c, kend_c, m0, n0, out_c;
+    float bias_r[TN];
+    auto begin_segment = [&](int i) {
+        const Seg g = get_seg(i);
         int tm, tn;
-        tile_coords(tile_c, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        tile_coords(g.tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
         m0 = tm * BM;
         n0 = tn * BN;
-    }
-    float bias_r[TN];
-    load_bias(n0, bias_r);
-
-    f32x16 acc[TM][TN];
+        k_c = g.k0;
+        kend_c = g.k1;
+        out_c = g.out;
+        if (g.out < 0) load_bias(n0, bias_r);  // consumed at the segment's end
+        if (SK && g.in >= 0) {
+            unpark(g.in);
+        } else {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+            for (int ii = 0; ii < TM; ++ii)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+                for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.0f;
+                    for (int v = 0; v < 16; ++v) acc[ii][jj][v] = 0.0f;
+        }
+    };
+    begin_segment(0);
 
     // ---- prologue (once per workgroup, not per tile): steps 0 and 1 -----------------------------
     load_step();
@@ -174,7 +276,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
 
     if constexpr (STAMP) st_loop0 = __builtin_amdgcn_s_memtime();
     int cur = 0;
-    const int steps = my_tiles * nk;
+    int steps = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const Seg g = get_seg(i);
+        steps += g.k1 - g.k0;
+    }
     for (int g = 0; g < steps; ++g) {
         const int k_ahead = k_l * PBK;  // offset of the step the restage loads fetch (step g + 2)
 #pragma unroll
@@ -201,30 +307,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
                     }
                 }
             }
-            if (c == 0) advance_load_cursor();  // scalar; re-bases the sources once per tile
+            if (c == 0) advance_load_cursor();  // scalar; re-bases the sources once per segment
         }
         cur ^= 1;
 
-        if (++k_c == nk) {  // tile finished: store it, restart the accumulators, move on
+        if (++k_c == kend_c) {  // segment finished: store the tile (or park the piece), start the next one
             unsigned long long e0 = 0;
             if constexpr (STAMP) e0 = __builtin_amdgcn_s_memtime();
-            epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h);
+            if (SK && out_c >= 0) park(out_c);
+            else epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h);
             if constexpr (STAMP) st_epi += __builtin_amdgcn_s_memtime() - e0;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.0f;
-            k_c = 0;
-            tile_c += nwg;
-            if (tile_c < total) {
-                int tm, tn;
-                tile_coords(tile_c, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-                m0 = tm * BM;
-                n0 = tn * BN;
-                load_bias(n0, bias_r);  // consumed a whole tile later
-            }
+            if (++seg_c < nseg) begin_segment(seg_c);
         }
     }
     if constexpr (STAMP) {
@@ -232,12 +325,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         if (tid == 0) {
             unsigned long long *d = p.dbg + (size_t)blockIdx.x * 8;
             d[0] = st0; d[1] = st_loop0; d[2] = st_epi; d[3] = c3; d[4] = st_rt0; d[5] = r3;
-            d[6] = (unsigned long long)my_tiles; d[7] = (unsigned long long)steps;
+            d[6] = (unsigned long long)nseg; d[7] = (unsigned long long)steps;
         }
     }
 }
 
 int g_persistent_wgs = 0;  // 2 per CU, queried once
+
+// K-steps of a last-round tile that a helper workgroup runs (0: the hand-over does not pay) for the 128 x 128 persistent walk
+int persistent_piece_steps(int M, int N, int K) {
+    if (g_persistent_wgs == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        g_persistent_wgs = 2 * cus;
+    }
+    const int total = ((M + 127) / 128) * ((N + 127) / 128);
+    const int nwg = total < g_persistent_wgs ? total : g_persistent_wgs;
+    const int full = total / nwg, R = total - full * nwg, nk = K / PBK;
+    if (full < 1 || R <= 0 || R >= nwg) return 0;
+    const int c = (R + (nwg - R) - 1) / (nwg - R);
+    const int x = nk / (c + 1);
+    // a hand-over costs about 3 K-steps (64 KB out, 64 KB in through uncached memory, the flag): worth it when the walk gets
+    // at least 12 steps shorter (measured at batch 256: fc2 -4.1 %, fc1 -0.8 %, out_proj 0: nk = 24, 8 saved)
+    return (x >= 4 && nk - c * x >= 12) ? x : 0;
+}
 
 template <int BM, int BN, int WM, int WN>
 int launch_persistent_tile(hipStream_t stream, GemmParams &p, int epilogue, int group_m) {
@@ -253,6 +364,25 @@ int launch_persistent_tile(hipStream_t stream, GemmParams &p, int epilogue, int 
     p.group_m = group_m;
     const int total = p.tiles_m * p.tiles_n;
     const dim3 grid(total < g_persistent_wgs ? total : g_persistent_wgs), block(256);
+    // helper pieces (see the head of this file): on when the caller lent a workspace, a partial last round exists and the
+    // piece is long enough to be worth a 64 KB hand-over (>= 4 K-steps)
+    p.sk_x = (p.sk_ws && BM == 128 && BN == 128) ? persistent_piece_steps(p.M, p.N, p.K) : 0;
+    if (p.sk_x > 0) {
+        switch (epilogue) {
+            case VITHIP_EPI_BIAS:
+                hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS, false, true>), grid, block, 0, stream, p);
+                break;
+            case VITHIP_EPI_BIAS_GELU:
+                hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS_GELU, false, true>), grid, block, 0, stream, p);
+                break;
+            case VITHIP_EPI_BIAS_RESIDUAL:
+                hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS_RESIDUAL, false, true>), grid, block, 0, stream, p);
+                break;
+            default:
+                return static_cast<int>(hipErrorInvalidValue);
+        }
+        return static_cast<int>(hipGetLastError());
+    }
     switch (epilogue) {
         case VITHIP_EPI_BIAS:
             hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS>), grid, block, 0, stream, p);

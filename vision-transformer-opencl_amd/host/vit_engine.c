@@ -42,6 +42,7 @@ struct vit_engine {
     float **w;                   /* device pointer per weight index */
     unsigned short *wblob16;     /* the bf16 section inside wblob (dtype bf16 only) */
     int lane_cap;                /* most images one lane may hold (32-bit buffer offsets of the fp32 kernels) */
+    void *gemm_ws[VIT_MAX_LANES]; /* per lane (= per stream): vithip_gemm_args.workspace, zeroed once */
     /* use_graph: the captured forward and what it was captured for */
     vithip_graph_t graph;
     const float *g_images; float *g_probs; int *g_label; float *g_prob; int g_n;
@@ -211,6 +212,8 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
     HIP_TRY(e, vithip_malloc((void **)&e->hbuf, B * T * H * sizeof(float)));
     HIP_TRY(e, vithip_malloc((void **)&e->z, B * D * sizeof(float)));
     HIP_TRY(e, vithip_malloc((void **)&e->logits, B * NC * sizeof(float)));
+    if (e->opt.dtype == VIT_DTYPE_F32)
+        for (int j = 0; j < VIT_MAX_LANES; ++j) HIP_TRY(e, vithip_gemm_f32_workspace_create(&e->gemm_ws[j]));
     HIP_TRY(e, vithip_stream_create(&e->copy_stream));
     for (int b = 0; b < 2; ++b) {
         HIP_TRY(e, vithip_malloc((void **)&e->in_stage[b], B * img * sizeof(float)));
@@ -241,6 +244,7 @@ void vit_engine_destroy(vit_engine *e) {
     if (e->graph) vithip_graph_destroy(e->graph);
     vithip_free(e->x); vithip_free(e->y); vithip_free(e->qkv); vithip_free(e->hbuf);
     vithip_free(e->z); vithip_free(e->logits);
+    for (int j = 0; j < VIT_MAX_LANES; ++j) vithip_gemm_f32_workspace_destroy(e->gemm_ws[j]);
     if (e->copy_stream) { vithip_stream_sync(e->copy_stream); vithip_stream_destroy(e->copy_stream); }
     for (int b = 0; b < 2; ++b) {
         vithip_free(e->in_stage[b]); vithip_free(e->out_stage[b]);
@@ -410,6 +414,10 @@ static int stage_end(vit_engine *e, vithip_stream_t s) {
 static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int lda, const float *W,
                 const float *bias, const float *res, float *C, int ldc, int M, int N, int K, int epi) {
     vithip_gemm_args a;
+    a.workspace = NULL; /* the lane's workspace: launches on one stream are ordered, which is what sharing it needs */
+    if (s == e->stream || e->opt.lanes == 1) a.workspace = e->gemm_ws[0];
+    for (int j = 0; j < VIT_MAX_LANES - 1; ++j)
+        if (s == e->aux_stream[j]) a.workspace = e->gemm_ws[j + 1];
     a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
     a.tile = e->opt.gemm_tile; a.group_m = 0;
