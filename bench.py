@@ -114,8 +114,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-forward-per-core aggregate CPU figure")
     ap.add_argument("--cpu-all-cores", type=int, default=16,
                     help="cap on concurrent single-threaded CPU forwards for cpu_baseline.all_cores (a 1-GPU box's CPU share is 16)")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="concurrent sub-batches per step (engine option; 1 = every kernel alone on the GPU)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="concurrent sub-batches per step (engine option; 1 = every kernel alone on the GPU).  Default: 1 for fp32 "
+                         "(its GEMMs balance their own tails and assume their workgroups resident), 2 for bf16 (the HBM-bound "
+                         "LayerNorm / residual kernels of one lane overlap the other's GEMMs: +6 %%)")
     ap.add_argument("--kernel-steps", type=int, default=3,
                     help="extra steps with lanes=1 and per-launch event brackets for the roofline object (when lanes > 1)")
     ap.add_argument("--model", choices=("b16", "l16_384"), default="b16",
@@ -139,6 +141,8 @@ def main() -> None:
                     help="start the rank processes from this process even for --gpus 1 (N > 1 always does when not "
                          "already launched): exercises the launcher and the RCCL gather at world size 1")
     args = ap.parse_args()
+    if args.lanes <= 0:
+        args.lanes = 1 if args.dtype == "f32" else 2
 
     # ---- one process per GPU -------------------------------------------------------------------------
     # `python bench.py --gpus N` started plainly: THIS process only spawns the N ranks (fresh interpreters, before

@@ -29,7 +29,7 @@
  * "0,1,2,3,4,5,6,7": one engine and one host thread per device, the weights uploaded once and replicated device to
  * device, image[0..n) split into contiguous slices -- the reference's image loop, ViT_opencl.c:802, cut across the
  * GPUs of the node; results are bit-identical to the single-device run); VIT_HIP_MAX_BATCH (chunk size per device,
- * default 256), VIT_HIP_LANES (concurrent sub-batches per chunk, default 1), VIT_HIP_DTYPE ("bf16" selects the bf16
+ * default 256), VIT_HIP_LANES (concurrent sub-batches per chunk, default 1 for fp32, 2 for bf16), VIT_HIP_DTYPE ("bf16" selects the bf16
  * matrix-pipe variant: same top-1, |dprob| <= 2e-2 against the fp32 reference instead of 1e-4; default fp32),
  * VIT_HIP_PRUNE_LAST_LAYER (1: vit_engine_options.prune_last_layer, bit-identical probabilities; default 0).
  */

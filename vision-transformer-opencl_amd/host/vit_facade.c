@@ -75,10 +75,12 @@ void initialize_hip(void) {
     vit_engine_options opt;
     vit_engine_default_options(&opt);
     opt.max_batch = env_int("VIT_HIP_MAX_BATCH", opt.max_batch);
-    opt.lanes = env_int("VIT_HIP_LANES", 1); /* concurrent sub-batches (bit-identical); 1 since the GEMMs balance their own tails */
     opt.prune_last_layer = env_int("VIT_HIP_PRUNE_LAST_LAYER", 0); /* bit-identical output, 7 % less arithmetic */
     const char *dt = getenv("VIT_HIP_DTYPE"); /* "bf16" = bf16 matrix pipe (own tolerance); default: the reference's fp32 */
     if (dt && (!strcmp(dt, "bf16") || !strcmp(dt, "BF16"))) opt.dtype = VIT_DTYPE_BF16;
+    /* concurrent sub-batches (bit-identical): fp32 1 -- its GEMMs balance their own tails and assume their workgroups resident;
+     * bf16 2 -- the HBM-bound LayerNorm / residual kernels of one lane overlap the other's GEMMs (+6 %) */
+    opt.lanes = env_int("VIT_HIP_LANES", opt.dtype == VIT_DTYPE_BF16 ? 2 : 1);
     vit_config cfg = vit_config_b16(); /* the reference's compile-time model (ViT_opencl.c:12-23) */
     int n = parse_devices(g_vit.device);
     if (n == 0) {
