@@ -111,6 +111,9 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
 size_t vithip_gemm_f32_workspace_bytes(void);
 int vithip_gemm_f32_workspace_create(void **workspace);   /* on the current device */
 int vithip_gemm_f32_workspace_destroy(void *workspace);
+/* after the stream's work is complete: *timed_out = 1 when an owner workgroup gave up (after ~60 ms) waiting for the piece a
+ * helper was to deliver -- its tile is then wrong; clears the mark.  A bounded wait instead of a hang. */
+int vithip_gemm_f32_workspace_check(void *workspace, int *timed_out);
 /* ---- bf16 variant (BASELINE.json configs[2]) ---------------------------------
  * bf16 values are raw uint16 (upper half of the fp32 bit pattern, round-to-nearest-even). */
 enum { VITHIP_BF16_EPI_BF16 = 0, VITHIP_BF16_EPI_BF16_GELU = 1, VITHIP_BF16_EPI_F32_RESIDUAL = 2,

@@ -457,6 +457,16 @@ int vithip_gemm_f32_workspace_create(void **ws) {
     return static_cast<int>(e);
 }
 int vithip_gemm_f32_workspace_destroy(void *ws) { return ws ? static_cast<int>(hipFree(ws)) : 0; }
+// *timed_out = 1 if, since the last check, an owner workgroup gave up waiting for its helper's piece (its tile is then wrong).
+// Blocking (the stream's work must be complete for the answer to mean anything); clears the mark.
+int vithip_gemm_f32_workspace_check(void *ws, int *timed_out) {
+    if (!ws || !timed_out) return static_cast<int>(hipErrorInvalidValue);
+    int mark = 0;
+    hipError_t e = hipMemcpy(&mark, static_cast<char *>(ws) + 4092, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mark) e = hipMemset(static_cast<char *>(ws) + 4092, 0, sizeof(int));
+    *timed_out = mark != 0;
+    return static_cast<int>(e);
+}
 
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);

@@ -222,6 +222,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
             int spins = 0;
             while (__hip_atomic_load(sk_flags + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 18))
                 __builtin_amdgcn_s_sleep(8);
+            // gave up: the result of this tile is wrong.  Leave a mark the host can see (vithip_gemm_f32_workspace_check)
+            if (spins >= (1 << 18)) __hip_atomic_store(sk_flags + 1023, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();  // (uncached memory: nothing stale to drop, see park())
         const f32x4 *src = slot_ptr(o) + tid;

@@ -801,6 +801,11 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
             memcpy(probs[first + i], e->pin_out[b] + (size_t)i * NC, NC * sizeof(float));
     }
 #undef PIECE_N
+    for (int j = 0; j < VIT_MAX_LANES; ++j) { /* everything above is complete: did a GEMM hand-over give up waiting? */
+        int timed_out = 0;
+        if (e->gemm_ws[j]) HIP_TRY(e, vithip_gemm_f32_workspace_check(e->gemm_ws[j], &timed_out));
+        if (timed_out) return fail(e, VIT_ERR_HIP, "a GEMM workgroup gave up waiting for its helper piece (lane %d): results are invalid", j);
+    }
     if (e->opt.profile) {
         int rc = collect_profile(e);
         if (rc) return rc;
