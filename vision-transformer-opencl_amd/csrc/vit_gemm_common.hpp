@@ -68,12 +68,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // chains advanced together -- the scheduling fences keep the compiler from re-serialising them --
 // issue back to back.
 __device__ __forceinline__ void gelu_erf_x8(float (&y)[8]) {
-    float u[8], t[8], q[8];
+    // the same arithmetic as gelu_erf() value by value (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 round like their scalar
+    // forms), two values per instruction where a packed form exists: the polynomial, the scalings and the final products --
+    // 21 VALU instructions per pair instead of 38.  Every one of them is paid for in fp32 matrix-pipe time (item 4 of DESIGN 4.1).
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 yy[4], u[4], t[4], q[4];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        u[v] = y[v] * 0.70710678118654752440f;
-        t[v] = fminf(fabsf(u[v]), 4.0f);
-        q[v] = fmaf(-3.144179208902642e-05f, t[v], 3.0881378916092217e-04f);
+    for (int v = 0; v < 4; ++v) {
+        yy[v] = v2{y[2 * v], y[2 * v + 1]};
+        u[v] = yy[v] * v2{0.70710678118654752440f, 0.70710678118654752440f};
+        t[v] = v2{fminf(fabsf(u[v][0]), 4.0f), fminf(fabsf(u[v][1]), 4.0f)};
+        q[v] = __builtin_elementwise_fma(v2{-3.144179208902642e-05f, -3.144179208902642e-05f}, t[v],
+                                         v2{3.0881378916092217e-04f, 3.0881378916092217e-04f});
     }
     __builtin_amdgcn_sched_barrier(0);
     constexpr float c[6] = {-1.0324339382350445e-03f, -5.368884885683656e-04f, 1.95839274674654e-02f,
@@ -81,17 +87,23 @@ __device__ __forceinline__ void gelu_erf_x8(float (&y)[8]) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) q[v] = fmaf(q[v], t[v], c[k]);
+        for (int v = 0; v < 4; ++v) q[v] = __builtin_elementwise_fma(q[v], t[v], v2{c[k], c[k]});
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int v = 0; v < 8; ++v) q[v] = q[v] * t[v] * 1.4426950408889634f;
+    for (int v = 0; v < 4; ++v) q[v] = q[v] * t[v] * v2{1.4426950408889634f, 1.4426950408889634f};
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int v = 0; v < 8; ++v) q[v] = __builtin_amdgcn_exp2f(q[v]);
+    for (int v = 0; v < 4; ++v) q[v] = v2{__builtin_amdgcn_exp2f(q[v][0]), __builtin_amdgcn_exp2f(q[v][1])};
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int v = 0; v < 8; ++v) y[v] = 0.5f * y[v] * (1.0f + copysignf(1.0f - q[v], u[v]));
+    for (int v = 0; v < 4; ++v) {
+        const v2 e = v2{1.0f, 1.0f} - q[v];
+        const v2 sgn = v2{copysignf(e[0], u[v][0]), copysignf(e[1], u[v][1])};
+        const v2 r = v2{0.5f, 0.5f} * yy[v] * (v2{1.0f, 1.0f} + sgn);
+        y[2 * v] = r[0];
+        y[2 * v + 1] = r[1];
+    }
 }
 
 // GELU for a bf16 destination, two values per instruction (v_pk_fma_f32 / v_pk_mul_f32).
