@@ -478,6 +478,9 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
         return static_cast<int>(hipErrorInvalidValue);  // 32-bit buffer offsets: split the batch (vit_engine's lane cap does)
     if (a->epilogue == VITHIP_EPI_BIAS_RESIDUAL && (!a->residual || a->ldr < a->N))
         return static_cast<int>(hipErrorInvalidValue);
+    if ((size_t)a->M * a->ldc * 4 >= 0x7fffffffull ||
+        (a->epilogue == VITHIP_EPI_BIAS_RESIDUAL && (size_t)a->M * a->ldr * 4 >= 0x7fffffffull))
+        return static_cast<int>(hipErrorInvalidValue);  // the epilogue addresses C and the residual through 32-bit buffer offsets too
     GemmParams p{};
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.R = a->residual; p.C = a->C;
     p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;

@@ -180,9 +180,15 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
 #pragma unroll
                     for (int v = 0; v < 16; ++v) p.C[orow[v] * p.ldc + n] = acc[i][j][v] + bias_r[j] + add[v];
                 } else {
-                    float *crow = p.C + (size_t)mb * p.ldc + n;
+                    // Buffer addressing: SGPR descriptor + ONE per-lane byte offset per accumulator + the row's offset as the
+                    // instruction's scalar operand.  With 64-bit pointers every one of the 16 rows cost vector address
+                    // arithmetic (matrix-pipe time on gfx950) and a register pair; the persistent residual kernel spilled.
+                    // The launcher keeps C and the residual below 2 GiB.
+                    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7fffffff, 0x00020000);
+                    const int c_off = (mb * p.ldc + n) * 4, c_row = p.ldc * 4;
                     if constexpr (EPI == VITHIP_EPI_BIAS_RESIDUAL) {
-                        const float *rrow = p.R + (size_t)mb * p.ldr + n;
+                        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.R), 0, 0x7fffffff, 0x00020000);
+                        const int r_off = (mb * p.ldr + n) * 4, r_row = p.ldr * 4;
                         // two batches of 8 loads-then-stores: enough in flight, half the registers
 #pragma unroll
                         for (int half = 0; half < 2; ++half) {
@@ -190,12 +196,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const int v = half * 8 + q;
-                                res[q] = rrow[(size_t)((v & 3) + 8 * (v >> 2)) * p.ldr];
+                                res[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, r_off, ((v & 3) + 8 * (v >> 2)) * r_row, 0));
                             }
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const int v = half * 8 + q;
-                                crow[(size_t)((v & 3) + 8 * (v >> 2)) * p.ldc] = acc[i][j][v] + bias_r[j] + res[q];
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][v] + bias_r[j] + res[q]), c_rsrc, c_off,
+                                                                      ((v & 3) + 8 * (v >> 2)) * c_row, 0);
                             }
                         }
                     } else {
@@ -209,7 +216,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const int v = half * 8 + q;
-                                crow[(size_t)((v & 3) + 8 * (v >> 2)) * p.ldc] = y[q];
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[q]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, 0);
                             }
                         }
                     }
