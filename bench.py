@@ -34,7 +34,7 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA (16x the fp32 matrix rate), no
 STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it at the metric configuration (fp32, batch 256, one lane)
     "qkv": "gemm_f32_nt_persistent_kernel<EPI_BIAS>", "head": "gemm_f32_nt_persistent_kernel<EPI_BIAS>",
     "fc1": "gemm_f32_nt_persistent_kernel<EPI_BIAS_GELU>",
-    "outproj": "gemm_f32_nt_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_persistent_kernel<EPI_BIAS_RESIDUAL>",
+    "outproj": "gemm_f32_nt_persistent_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_persistent_kernel<EPI_BIAS_RESIDUAL>",
     "attn": "attention_f32_resident_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
     "softmax": "softmax_top1_f32_kernel",
 }

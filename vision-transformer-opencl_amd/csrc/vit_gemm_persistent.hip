@@ -348,8 +348,9 @@ int persistent_piece_steps(int M, int N, int K) {
     const int c = (R + (nwg - R) - 1) / (nwg - R);
     const int x = nk / (c + 1);
     // a hand-over costs about 3 K-steps (64 KB out, 64 KB in through uncached memory, the flag): worth it when the walk gets
-    // at least 12 steps shorter (measured at batch 256: fc2 -4.1 %, fc1 -0.8 %, out_proj 0: nk = 24, 8 saved)
-    return (x >= 4 && nk - c * x >= 12) ? x : 0;
+    // at least 8 steps shorter (measured at batch 256: fc2 -5 %, out_proj -5 % (nk = 24, 8 of 120 saved), fc1 -1.7 %;
+    // QKV would save 6 of 336 with six 3-step pieces per helper: off)
+    return (x >= 4 && nk - c * x >= 8) ? x : 0;
 }
 
 template <int BM, int BN, int WM, int WN>
