@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Time vithip_gemm_bf16 (product library, or the one VIT_HIP_LIBRARY names) at the ViT shapes.  GPU box only.
+
+    python tools/gemm_bf16_time.py [batch] [b16|l16_384]
+"""
+import ctypes as C, importlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+B = importlib.import_module("vision-transformer-opencl_amd.binding")
+from tools.gemm_probe import timed
+L = B.lib()
+L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(B.CGemmBf16Args)]
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+model = sys.argv[2] if len(sys.argv) > 2 else "b16"
+T, D = (197, 768) if model == "b16" else (577, 1024)
+M = batch * T
+SHAPES = {"qkv": (M, 3 * D, D, 0), "outproj": (M, D, D, 2), "fc1": (M, 4 * D, D, 1), "fc2": (M, D, 4 * D, 2)}
+out = {}
+for name, (M_, N, K, epi) in SHAPES.items():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0x3c00, 0x4000, size=(M_, K), dtype=np.uint16)
+    a[::2] |= 0x8000
+    dA = B.DeviceArray.from_numpy(a)
+    dW = B.DeviceArray.from_numpy(B.to_bf16_bits(rng.uniform(-.05, .05, (N, K)).astype(np.float32)))
+    db = B.DeviceArray.from_numpy(rng.uniform(-.1, .1, (N,)).astype(np.float32))
+    dC = B.DeviceArray((M_, N), np.float32 if epi == 2 else np.uint16)
+    args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi, 0, 0, 0)
+    ms = min(timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=5, warm=2) for _ in range(3))
+    out[name] = {"ms": round(ms, 4), "tflops": round(2.0 * M_ * N * K / (ms * 1e-3) / 1e12, 1)}
+    for d in (dA, dW, db, dC):
+        d.free()
+print(json.dumps({"library": os.path.basename(B.LIB_PATH), "batch": batch, "model": model, **out}))
