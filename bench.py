@@ -136,6 +136,8 @@ def main() -> None:
     ap.set_defaults(no_stage_brackets=True)
     ap.add_argument("--graph", action="store_true",
                     help="vit_engine_options.use_graph: replay the forward as one hipGraph (needs --lanes 1; small batches)")
+    ap.add_argument("--ln-fold", type=int, default=0, choices=(-1, 0, 1),
+                    help="bf16: fold the encoder LayerNorms into the GEMMs either side (0 auto = on, -1 off: LayerNorm kernels)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes from this process even for --gpus 1 (N > 1 always does when not "
@@ -183,7 +185,7 @@ def main() -> None:
     # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
     # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
     eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1 and not args.graph and not args.no_stage_brackets), lanes=args.lanes,
-                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph, gemm_tile=args.gemm_tile)
+                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph, gemm_tile=args.gemm_tile, ln_fold=args.ln_fold)
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the
@@ -368,7 +370,7 @@ def main() -> None:
                                     "(BASELINE.json configs[%d])" % (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2))),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                        "top1_gather": ("rccl all_gather, 8 B per image" + ("" if gather_ok else " (MISMATCH)")) if distributed else None,
-                       "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "device": info["name"], "arch": info["arch"],
+                       "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "ln_fold": (args.ln_fold >= 0) if args.dtype == "bf16" else False, "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }))

@@ -49,6 +49,10 @@ typedef struct {
                       * small batches the ~150 launches of a forward are a visible share of the latency.  Ignored
                       * while profiling, with lanes > 1 and on the NULL stream (not capturable). */
     int gemm_tile;   /* tuning: vithip_gemm_args.tile for every fp32 GEMM of this engine (0 = auto, the default) */
+    int ln_fold;     /* bf16 engines: fold the encoder LayerNorms into the GEMMs either side of them (vit_hip_kernels.h,
+                      * "LayerNorm folding"): 0 = auto (on when embed_dim and hidden_dim >= 128), 1 = on (error when the
+                      * shapes do not allow it), -1 = off (a LayerNorm kernel per LayerNorm).  Not used by fp32 engines:
+                      * the fp32 path keeps the reference's operation order. */
 } vit_engine_options;
 
 enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };

@@ -132,11 +132,39 @@ typedef struct {
      * two_barriers: barrier schedule of the ping-pong kernel, 0 = one barrier per phase and wave (default), 1 = two;
      * stagger: start-up skew between its persistent workgroups, units of 512 cycles per position in the XCD (0..64). */
     int variant, two_barriers, stagger;
+    /* LayerNorm folded into the GEMMs either side of it (all NULL = off; ping-pong kernel only, i.e. K >= 128):
+     * producer, EPI_F32_RESIDUAL with x16 and row_partials set: besides C the epilogue stores bf16(C) to x16 [M][ldx16]
+     *   (ldx16 % 8 == 0, 16-byte aligned) and the partial (sum, sum of squares) of every row over every 64-column strip to
+     *   row_partials [vithip_ln_strips(N)][M][2]; vithip_rowstats_finalize() turns them into ln_rows;
+     * consumer, EPI_BF16 / EPI_BF16_GELU with ln_rows and ln_colsum set: A is the UN-normalised bf16 row, W and bias are the
+     *   gamma- and beta-folded operands of vithip_ln_fold_weights(), ln_rows [M][2] = (rstd, mean * rstd) per row of A and
+     *   ln_colsum [N]; the epilogue computes rstd * acc - (mean * rstd) * colsum + bias = LayerNorm(x) . W^T + b. */
+    const float *ln_rows, *ln_colsum;
+    unsigned short *x16; int ldx16;
+    float *row_partials;
 } vithip_gemm_bf16_args;
 /* C = epilogue(A . W^T + bias) on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16 in the ping-pong kernel,
  * v_mfma_f32_32x32x16_bf16 in the two-stage one), fp32 accumulate.  BF16_GELU rounds gelu(acc + bias) to bf16 (a
  * polynomial erfc whose error stays below 5 % of half a bf16 ulp); F32_RESIDUAL adds an fp32 residual in fp32. */
 int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
+/* ---- LayerNorm folding (bf16 forward): LN(x) . W^T + b = rstd * (x . (gamma*W)^T) - rstd * mean * colsum(gamma*W) + (b + W . beta),
+ * so the normalised activations never exist in memory: the residual GEMM in front stores bf16(x) and row sums, the GEMM
+ * behind multiplies the raw bf16 rows with the folded weight and rescales in its epilogue (ViT_seq.c:103-121 is the
+ * LayerNorm being folded: mean, var = E[x^2] - mean^2, 1/sqrt(var + 1e-6)). */
+/* Wf[n][k] = bf16(gamma[k] * W[n][k]); colsum[n] = sum_k float(Wf[n][k]) (the ROUNDED values: the mean term then cancels
+ * exactly what the matrix pipe accumulates); bias_f[n] = bias[n] + sum_k beta[k] * W[n][k].  W fp32 [N][K], K % 4 == 0. */
+int vithip_ln_fold_weights(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
+                           unsigned short *Wf, float *colsum, float *bias_f, int N, int K);
+/* x16 = bf16(x) and rows[m] = (rstd, mean * rstd) of fp32 rows x [rows][ldx] (the first LayerNorm of the stack, which has no
+ * residual GEMM in front of it). */
+int vithip_rowstats_bf16(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *x16, size_t ldx16,
+                         float *rows_out, int rows, int dim);
+/* strips = vithip_ln_strips(N) = 4 * ceil(N / 256): partials [strips][rows][2] (sum, sum of squares) -> rows_out [rows][2]. */
+int vithip_ln_strips(int N);
+int vithip_rowstats_finalize(vithip_stream_t stream, const float *partials, int strips, int rows, int dim, float *rows_out);
+/* dst[r][0..width) = src[r * src_stride .. + width): a strided row subset made compact (e.g. the pairs of the class rows). */
+int vithip_gather_rows_f32(vithip_stream_t stream, const float *src, size_t src_stride, float *dst, size_t dst_stride, int rows,
+                           int width);
 /* LayerNorm with fp32 statistics and a bf16 store; attention reading bf16 Q/K/V [n*tokens][3*heads*64] and
  * writing bf16 [n*tokens][heads*64]: both products on bf16 MFMA with fp32 softmax (P rounded to bf16 once);
  * vithip_attention_bf16io_f32math: same I/O, K/V widened to fp32 in LDS and the fp32 kernel's arithmetic (cross-check). */

@@ -134,11 +134,18 @@ def test_attention_bf16_io(oracle, n, T, heads, mfma):
 BF16_PROB_TOL = 2e-2   # bf16 activations carry 8 significant bits; the fp32 bar (1e-4) does not apply here
 
 
+@pytest.fixture(params=[0, -1], ids=["ln-folded", "ln-kernels"])
+def ln_fold(request):
+    """vit_engine_options.ln_fold: 0 = auto (the encoder LayerNorms folded into the GEMMs either side wherever the widths allow:
+    every model here but VIT_TINY), -1 = one LayerNorm kernel per LayerNorm.  Both must meet the same bar."""
+    return request.param
+
+
 @pytest.mark.parametrize("cfg,n", [(synth.VIT_TINY, 5), (synth.VIT_SMALL, 6)])
-def test_bf16_forward_small_models(oracle, cfg, n):
+def test_bf16_forward_small_models(oracle, cfg, n, ln_fold):
     from conftest import oracle_config
     W = synth.make_weights(cfg, 21)
-    eng = B.Engine(cfg, max_batch=4, dtype="bf16")
+    eng = B.Engine(cfg, max_batch=4, dtype="bf16", ln_fold=ln_fold)
     eng.load_weights(W)
     imgs = synth.make_images(cfg, n, 100)
     probs = eng.forward(imgs)
@@ -148,13 +155,13 @@ def test_bf16_forward_small_models(oracle, cfg, n):
     eng.close()
 
 
-def test_bf16_forward_b16_vs_reference_golden():
+def test_bf16_forward_b16_vs_reference_golden(ln_fold):
     """ViT-B/16 with bf16 MFMA GEMMs against the fp32 reference vectors: same top-1, probabilities within
     BF16_PROB_TOL (measured 2.4e-3)."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vit_b16_e2e.npz"))
     cfg = synth.VIT_B16
-    eng = B.Engine(cfg, max_batch=8, dtype="bf16", lanes=2)
+    eng = B.Engine(cfg, max_batch=8, dtype="bf16", lanes=2, ln_fold=ln_fold)
     eng.load_weights(synth.make_weights(cfg, int(g["weight_seed"])))
     imgs = synth.make_images(cfg, int(g["n_images"]), int(g["image_seed"]))
     probs = eng.forward(imgs)
@@ -165,13 +172,13 @@ def test_bf16_forward_b16_vs_reference_golden():
     eng.close()
 
 
-def test_bf16_forward_vit_l_geometry(oracle):
+def test_bf16_forward_vit_l_geometry(oracle, ln_fold):
     """ViT-L/16-384 width and sequence length (D=1024, 16 heads, H=4096, 577 tokens), 2 layers, bf16 GEMMs
     (K = 1024 / 4096) + the chunked attention with bf16 I/O, against the fp32 oracle."""
     from conftest import oracle_config
     cfg = synth.ModelConfig(img_size=384, embed_dim=1024, depth=2, num_heads=16, hidden_dim=4096)
     W = synth.make_weights(cfg, 31)
-    eng = B.Engine(cfg, max_batch=2, dtype="bf16")
+    eng = B.Engine(cfg, max_batch=2, dtype="bf16", ln_fold=ln_fold)
     eng.load_weights(W)
     imgs = synth.make_images(cfg, 2, 32)
     probs = eng.forward(imgs)
@@ -179,6 +186,36 @@ def test_bf16_forward_vit_l_geometry(oracle):
     assert float(np.abs(probs - ref).max()) <= BF16_PROB_TOL
     assert (probs.argmax(1) == ref.argmax(1)).all()
     eng.close()
+
+
+def test_ln_fold_is_invariant_to_lanes_chunks_and_pruning():
+    """The folded forward keeps the engine's invariances: the same bits whatever the lane split, the chunking, the position in
+    the batch (row sums are added in a fixed order, no atomics) or exact last-layer pruning (the class rows go through the same
+    folded GEMMs with their own (rstd, mean*rstd) pairs).  Folded vs LayerNorm kernels: close, not equal."""
+    cfg = synth.ModelConfig(img_size=64, embed_dim=256, depth=3, num_heads=4, hidden_dim=512, num_classes=100)
+    W = synth.make_weights(cfg, 77)
+    imgs = synth.make_images(cfg, 11, 78)
+    outs = {}
+    for key, kw in {"base": dict(max_batch=16), "lanes3": dict(max_batch=16, lanes=3), "chunks": dict(max_batch=4, lanes=2),
+                    "pruned": dict(max_batch=16, prune_last_layer=True), "kernels": dict(max_batch=16, ln_fold=-1)}.items():
+        eng = B.Engine(cfg, dtype="bf16", **kw)
+        eng.load_weights(W)
+        outs[key] = eng.forward(imgs)
+        eng.close()
+    for same in ("lanes3", "chunks", "pruned"):
+        assert np.array_equal(outs[same], outs["base"]), same
+    assert np.array_equal(outs["base"][::-1], B_forward_reversed(cfg, W, imgs))
+    d = float(np.abs(outs["kernels"] - outs["base"]).max())
+    assert 0 < d <= 5e-3, d
+    assert (outs["kernels"].argmax(1) == outs["base"].argmax(1)).all()
+
+
+def B_forward_reversed(cfg, W, imgs):
+    eng = B.Engine(cfg, max_batch=16, dtype="bf16")
+    eng.load_weights(W)
+    out = eng.forward(imgs[::-1].copy())
+    eng.close()
+    return out
 
 
 def test_facade_bf16_by_environment():

@@ -1,0 +1,99 @@
+"""LayerNorm folded into the bf16 GEMMs either side of it (bf16 variant; the LayerNorm is ViT_seq.c:103-121).
+
+    LN(x) . W^T + b  =  rstd * (x . (gamma*W)^T)  -  rstd * mean * colsum(gamma*W)  +  (b + W . beta)
+
+Producer = the residual GEMM in front (stores bf16(x) and per-row partial sums), consumer = the GEMM behind (raw bf16 rows,
+folded weight, epilogue rescale).  References are float64 numpy on the same bf16-exact operands; tolerances are written where used.
+"""
+import numpy as np
+import pytest
+
+from vit_amd import binding as B
+from vit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def u(k, shape, a, seed=4242):
+    return synth.uniform(seed, k, int(np.prod(shape)), -a, a).reshape(shape)
+
+
+def ln_rows_ref(x):
+    """(rstd, mean * rstd) per row, the reference's definition: var = E[x^2] - mean^2, 1/sqrt(var + 1e-6)."""
+    x = x.astype(np.float64)
+    mean = x.mean(axis=1)
+    var = (x * x).mean(axis=1) - mean * mean
+    rstd = 1.0 / np.sqrt(var + 1e-6)
+    return np.stack([rstd, mean * rstd], axis=1)
+
+
+def test_fold_weights_matches_definition():
+    N, K = 300, 768
+    W, b, g, be = u(0, (N, K), 0.05), u(1, (N,), 0.1), 1.0 + u(2, (K,), 0.5), u(3, (K,), 0.2)
+    Wf, cs, bf = B.ln_fold_weights(W, b, g, be)
+    assert np.array_equal(Wf, B.to_bf16_bits(g[None, :] * W))                       # one fp32 multiply, one bf16 rounding
+    assert np.allclose(cs, B.from_bf16_bits(Wf).astype(np.float64).sum(axis=1), rtol=0, atol=2e-5)   # sums of the ROUNDED values
+    assert np.allclose(bf, b + W.astype(np.float64) @ be.astype(np.float64), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("rows,dim", [(1000, 768), (77, 1024), (5, 64)])
+def test_rowstats_bf16(rows, dim):
+    x = u(4, (rows, dim), 2.0) + u(5, (rows, 1), 1.0)          # rows with different means
+    x16, rs = B.rowstats_bf16(x)
+    assert np.array_equal(x16, B.to_bf16_bits(x))
+    assert np.allclose(rs, ln_rows_ref(x), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 3 + 37, 768, 768), (600, 1024, 256), (256 * 70 + 5, 768, 128), (130, 320, 192)])
+def test_producer_stores_bf16_copy_and_row_sums(M, N, K):
+    """The residual epilogue with the fold: C bit-identical to the plain residual epilogue, x16 = bf16(C), and the strips' partial
+    sums add up to the row sums (fp32 summation order only).  Shapes: ragged last tile row, more tiles than workgroups, N not a
+    multiple of the tile (320: the strips of the absent columns must come out as zeros)."""
+    Ab, Wb, b, R = B.to_bf16_bits(u(6, (M, K), 1.0)), B.to_bf16_bits(u(7, (N, K), 0.05)), u(8, (N,), 0.1), u(9, (M, N), 2.0)
+    plain = B.gemm_bf16(Ab, Wb, b, residual=R, epilogue=B.BF16_EPI_F32_RESIDUAL)
+    Cf, x16, part = B.gemm_bf16(Ab, Wb, b, residual=R, epilogue=B.BF16_EPI_F32_RESIDUAL, ln_producer=True)
+    assert np.array_equal(Cf, plain)
+    assert np.array_equal(x16, B.to_bf16_bits(Cf))
+    assert part.shape == (B.ln_strips(N), M, 2)
+    c64 = Cf.astype(np.float64)
+    for k in range(part.shape[0]):                                                 # every strip on its own
+        cols = c64[:, 64 * k:64 * (k + 1)]
+        assert np.allclose(part[k, :, 0], cols.sum(axis=1), rtol=0, atol=2e-4), k
+        assert np.allclose(part[k, :, 1], (cols * cols).sum(axis=1), rtol=2e-6, atol=2e-4), k
+    rs = B.rowstats_finalize(part, N)
+    assert np.allclose(rs, ln_rows_ref(Cf), rtol=5e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("epi", [B.BF16_EPI_BF16, B.BF16_EPI_BF16_GELU])
+@pytest.mark.parametrize("M,N,K", [(515, 2304, 768), (256 * 40 + 3, 1024 + 4, 256), (197, 3072, 768)])
+def test_consumer_equals_layernorm_then_gemm(epi, M, N, K):
+    """rstd * (x16 . Wf^T) - mean*rstd * colsum + bias_f against float64 LayerNorm(x16) . W^T + b on the same bf16 rows; the only
+    differences are the bf16 rounding of gamma*W (2^-9 relative per weight, a random walk over K) and fp32 accumulation, then one
+    bf16 rounding of the result.  Rows carry a mean of the size of their spread, so the mean term matters."""
+    x = u(10, (M, K), 1.5) + u(11, (M, 1), 1.0)
+    W, b, g, be = u(12, (N, K), 0.05), u(13, (N,), 0.1), 1.0 + u(14, (K,), 0.5), u(15, (K,), 0.2)
+    x16, rs = B.rowstats_bf16(x)
+    Wf, cs, bf = B.ln_fold_weights(W, b, g, be)
+    got = B.from_bf16_bits(B.gemm_bf16(x16, Wf, bf, epilogue=epi, ln_rows=rs, ln_colsum=cs))
+    xb = B.from_bf16_bits(x16).astype(np.float64)
+    rs64 = ln_rows_ref(x)                                       # statistics of the fp32 rows, as the engine has them
+    y = (xb * rs64[:, :1] - rs64[:, 1:]) * g + be               # LayerNorm of the rounded rows with those statistics
+    ref = y @ W.astype(np.float64).T + b
+    if epi == B.BF16_EPI_BF16_GELU:
+        from scipy.special import erf
+        ref = 0.5 * ref * (1.0 + erf(ref / np.sqrt(2.0)))
+    # bf16(gamma * W): independent relative errors uniform in +-2^-9 per weight -> sigma of their sum; 7 sigma over ~1e7 outputs
+    sigma = 2.0 ** -9 / np.sqrt(3.0) * np.sqrt((y * y) @ ((g * W).astype(np.float64) ** 2).T)
+    err = np.abs(got - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 7.0 * sigma + 1e-4).all(), float((err - 2.0 ** -8 * np.abs(ref) - 7.0 * sigma).max())
+
+
+def test_fold_arguments_are_validated():
+    Ab, Wb, b = B.to_bf16_bits(u(16, (256, 128), 1.0)), B.to_bf16_bits(u(17, (256, 128), 0.1)), np.zeros(256, np.float32)
+    rs, cs = np.ones((256, 2), np.float32), np.zeros(256, np.float32)
+    with pytest.raises(RuntimeError):      # consumer operands on the residual epilogue
+        B.gemm_bf16(Ab, Wb, b, residual=np.zeros((256, 256), np.float32), epilogue=B.BF16_EPI_F32_RESIDUAL, ln_rows=rs, ln_colsum=cs)
+    with pytest.raises(RuntimeError):      # only one of the two consumer operands
+        B.gemm_bf16(Ab, Wb, b, epilogue=B.BF16_EPI_BF16, ln_rows=rs)
+    with pytest.raises(RuntimeError):      # the two-stage kernel has no fold
+        B.gemm_bf16(Ab, Wb, b, epilogue=B.BF16_EPI_BF16, ln_rows=rs, ln_colsum=cs, variant=1)

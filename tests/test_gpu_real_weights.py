@@ -75,6 +75,24 @@ def test_out_proj_residual_and_ln2_on_real_weights(g):
         assert err <= 2e-2 * lin_mag, int(l)
         zb = B.from_bf16_bits(B.layernorm_bf16out(r, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"]))
         assert np.abs(zb[rows] - want_z).max() <= 2.0 ** -8 * mag(want_z) + 2e-5, int(l)
+        # LayerNorm folded into the GEMMs either side (the bf16 engine's default): real out_proj in front (bf16 copy + row sums of
+        # the residual stream with its massive channels), the real ln_2 gamma / beta folded into an fc1-shaped weight behind.
+        # Reference: the compiled reference's own LayerNorm rows (fp32) times that weight in float64.
+        _, x16, part = B.gemm_bf16(a16, w16, ob, residual=xres, epilogue=B.BF16_EPI_F32_RESIDUAL, ln_producer=True)
+        assert np.array_equal(x16, B.to_bf16_bits(rb))
+        rs = B.rowstats_finalize(part, rb.shape[1])
+        W1 = synth.uniform(seed, 900 + int(l), 512 * rb.shape[1], -0.05, 0.05).reshape(512, rb.shape[1])
+        b1 = synth.uniform(seed, 950 + int(l), 512, -0.1, 0.1)
+        Wf, cs, bf = B.ln_fold_weights(W1, b1, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"])
+        got = B.from_bf16_bits(B.gemm_bf16(x16, Wf, bf, epilogue=B.BF16_EPI_BF16, ln_rows=rs, ln_colsum=cs))[rows]
+        z64 = want_z.astype(np.float64)
+        ref = z64 @ W1.astype(np.float64).T + b1
+        sigma = 2.0 ** -9 / np.sqrt(3.0) * np.sqrt(2.0 * ((z64 * z64) @ (W1.astype(np.float64) ** 2).T))   # x and gamma*W both rounded once
+        err = np.abs(got - ref)
+        print(f"layer {int(l)}: folded LN2 + fc1-shaped GEMM on real gamma/beta: max |d| = {float(err.max()):.4f} of {mag(ref):.2f}")
+        # + the bf16 out_proj's own distance to the fp32 residual rows (asserted above), carried through LayerNorm and W1
+        carried = np.abs((rb[rows] - want_r).astype(np.float64) * rs[rows, :1] * g[f"ln2_w_{l}"]) @ np.abs(W1.astype(np.float64)).T
+        assert (err <= 2.0 ** -8 * np.abs(ref) + 7.0 * sigma + carried + 1e-4).all(), int(l)
 
 
 def test_final_ln_and_head_on_real_weights(g):

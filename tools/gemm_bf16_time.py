@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time vithip_gemm_bf16 (product library, or the one VIT_HIP_LIBRARY names) at the ViT shapes.  GPU box only.
 
-    python tools/gemm_bf16_time.py [batch] [b16|l16_384]
+    python tools/gemm_bf16_time.py [batch] [b16|l16_384] [fold]     fold: the LayerNorm-folded forms (consumer qkv / fc1, producer outproj / fc2)
 """
 import ctypes as C, importlib, json, os, sys
 import numpy as np
@@ -13,6 +13,7 @@ L = B.lib()
 L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(B.CGemmBf16Args)]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 model = sys.argv[2] if len(sys.argv) > 2 else "b16"
+fold = len(sys.argv) > 3 and sys.argv[3] == "fold"
 T, D = (197, 768) if model == "b16" else (577, 1024)
 M = batch * T
 SHAPES = {"qkv": (M, 3 * D, D, 0), "outproj": (M, D, D, 2), "fc1": (M, 4 * D, D, 1), "fc2": (M, D, 4 * D, 2)}
@@ -25,9 +26,19 @@ for name, (M_, N, K, epi) in SHAPES.items():
     dW = B.DeviceArray.from_numpy(B.to_bf16_bits(rng.uniform(-.05, .05, (N, K)).astype(np.float32)))
     db = B.DeviceArray.from_numpy(rng.uniform(-.1, .1, (N,)).astype(np.float32))
     dC = B.DeviceArray((M_, N), np.float32 if epi == 2 else np.uint16)
-    args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi, 0, 0, 0)
+    extra = []
+    if fold and epi == 2:
+        extra = [B.DeviceArray((M_, N), np.uint16), B.DeviceArray((B.ln_strips(N), M_, 2), np.float32)]
+        tail = (None, None, extra[0].ptr, N, extra[1].ptr)
+    elif fold:
+        extra = [B.DeviceArray.from_numpy(rng.uniform(0.5, 1.5, (M_, 2)).astype(np.float32)),
+                 B.DeviceArray.from_numpy(rng.uniform(-.1, .1, (N,)).astype(np.float32))]
+        tail = (extra[0].ptr, extra[1].ptr, None, 0, None)
+    else:
+        tail = (None, None, None, 0, None)
+    args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi, 0, 0, 0, *tail)
     ms = min(timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=5, warm=2) for _ in range(3))
     out[name] = {"ms": round(ms, 4), "tflops": round(2.0 * M_ * N * K / (ms * 1e-3) / 1e12, 1)}
-    for d in (dA, dW, db, dC):
+    for d in [dA, dW, db, dC] + extra:
         d.free()
-print(json.dumps({"library": os.path.basename(B.LIB_PATH), "batch": batch, "model": model, **out}))
+print(json.dumps({"library": os.path.basename(B.LIB_PATH), "batch": batch, "model": model, "fold": fold, **out}))

@@ -48,7 +48,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
-                ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int)]
+                ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int), ("ln_fold", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -233,7 +233,9 @@ class CGemmBf16Args(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int), ("bias", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
-                ("variant", C.c_int), ("two_barriers", C.c_int), ("stagger", C.c_int)]
+                ("variant", C.c_int), ("two_barriers", C.c_int), ("stagger", C.c_int),
+                ("ln_rows", C.c_void_p), ("ln_colsum", C.c_void_p), ("x16", C.c_void_p), ("ldx16", C.c_int),
+                ("row_partials", C.c_void_p)]
 
 
 BF16_EPI_BF16, BF16_EPI_BF16_GELU, BF16_EPI_F32_RESIDUAL = 0, 1, 2
@@ -261,9 +263,11 @@ def f32_to_bf16_device(x: np.ndarray) -> np.ndarray:
 
 
 def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16, variant: int = 0, two_barriers: bool = False,
-              stagger: int = 0) -> np.ndarray:
+              stagger: int = 0, ln_rows=None, ln_colsum=None, ln_producer: bool = False):
     """vithip_gemm_bf16 on bf16 bit patterns; returns bf16 bits (uint16) or fp32 for the residual epilogue.
-    variant: 0 auto, 1 two-stage kernel, 2 ping-pong kernel (fails for K < 128); two_barriers: its other barrier schedule."""
+    variant: 0 auto, 1 two-stage kernel, 2 ping-pong kernel (fails for K < 128); two_barriers: its other barrier schedule.
+    LayerNorm fold: ln_rows [M][2] + ln_colsum [N] make this the consumer; ln_producer (residual epilogue) also returns
+    (C, bf16(C) bits, row partials [strips][M][2])."""
     L = lib()
     L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(CGemmBf16Args)]
     M, K = A_bits.shape
@@ -273,10 +277,56 @@ def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16, varia
     out_f32 = epilogue == BF16_EPI_F32_RESIDUAL
     dC = DeviceArray((M, N), np.float32 if out_f32 else np.uint16)
     dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
+    dRows = DeviceArray.from_numpy(_as_f32(ln_rows)) if ln_rows is not None else None
+    dCs = DeviceArray.from_numpy(_as_f32(ln_colsum)) if ln_colsum is not None else None
+    strips = ln_strips(N)
+    dX16 = DeviceArray((M, N), np.uint16) if ln_producer else None
+    dPart = DeviceArray((strips, M, 2), np.float32) if ln_producer else None
     args = CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue,
-                         variant, 1 if two_barriers else 0, stagger)
+                         variant, 1 if two_barriers else 0, stagger, dRows.ptr if dRows else None, dCs.ptr if dCs else None,
+                         dX16.ptr if dX16 else None, N, dPart.ptr if dPart else None)
     hip_check(L.vithip_gemm_bf16(None, C.byref(args)), "vithip_gemm_bf16")
+    if ln_producer:
+        return dC.numpy(), dX16.numpy(), dPart.numpy()
     return dC.numpy()
+
+
+def ln_strips(N: int) -> int:
+    return int(lib().vithip_ln_strips(int(N)))
+
+
+def ln_fold_weights(W, bias, gamma, beta):
+    """vithip_ln_fold_weights -> (Wf bf16 bits [N][K], colsum [N], bias_f [N])."""
+    W = _as_f32(W)
+    N, K = W.shape
+    L = lib()
+    L.vithip_ln_fold_weights.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int]
+    dW, db, dg, dbe = (DeviceArray.from_numpy(_as_f32(a)) for a in (W, bias, gamma, beta))
+    dWf, dcs, dbf = DeviceArray((N, K), np.uint16), DeviceArray((N,), np.float32), DeviceArray((N,), np.float32)
+    hip_check(L.vithip_ln_fold_weights(None, dW.ptr, db.ptr, dg.ptr, dbe.ptr, dWf.ptr, dcs.ptr, dbf.ptr, N, K), "vithip_ln_fold_weights")
+    return dWf.numpy(), dcs.numpy(), dbf.numpy()
+
+
+def rowstats_bf16(x):
+    """vithip_rowstats_bf16 -> (bf16(x) bits, rows [M][2] = (rstd, mean * rstd))."""
+    x = _as_f32(x)
+    rows, dim = x.shape
+    L = lib()
+    L.vithip_rowstats_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    dx, d16, dr = DeviceArray.from_numpy(x), DeviceArray((rows, dim), np.uint16), DeviceArray((rows, 2), np.float32)
+    hip_check(L.vithip_rowstats_bf16(None, dx.ptr, dim, d16.ptr, dim, dr.ptr, rows, dim), "vithip_rowstats_bf16")
+    return d16.numpy(), dr.numpy()
+
+
+def rowstats_finalize(partials, dim: int):
+    """vithip_rowstats_finalize: partials [strips][M][2] -> rows [M][2]."""
+    partials = _as_f32(partials)
+    strips, rows, _ = partials.shape
+    L = lib()
+    L.vithip_rowstats_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    dp, dr = DeviceArray.from_numpy(partials), DeviceArray((rows, 2), np.float32)
+    hip_check(L.vithip_rowstats_finalize(None, dp.ptr, strips, rows, dim, dr.ptr), "vithip_rowstats_finalize")
+    return dr.numpy()
 
 
 def layernorm_bf16out(x, gamma, beta) -> np.ndarray:
@@ -398,12 +448,12 @@ class Engine:
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
                  lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False,
-                 gemm_tile: int = 0):
+                 gemm_tile: int = 0, ln_fold: int = 0):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
         opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
-                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile)
+                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

@@ -426,6 +426,23 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
     if (a->variant < 0 || a->variant > 2 || a->stagger < 0 || a->stagger > 64) return static_cast<int>(hipErrorInvalidValue);
+    // LayerNorm fold: consumer (ln_rows + ln_colsum on the bf16 epilogues) or producer (x16 + row_partials on the residual one)
+    const bool ln_consumer = a->ln_rows || a->ln_colsum, ln_producer = a->x16 || a->row_partials;
+    if (ln_consumer) {
+        if (!a->ln_rows || !a->ln_colsum || ln_producer || (a->epilogue != VITHIP_BF16_EPI_BF16 && a->epilogue != VITHIP_BF16_EPI_BF16_GELU) ||
+            (reinterpret_cast<size_t>(a->ln_rows) & 7) || !aligned16(a->ln_colsum))
+            return static_cast<int>(hipErrorInvalidValue);
+        p.ln_rows = a->ln_rows;
+        p.ln_colsum = a->ln_colsum;
+    }
+    if (ln_producer) {
+        if (!a->x16 || !a->row_partials || a->epilogue != VITHIP_BF16_EPI_F32_RESIDUAL || a->ldx16 < a->N || a->ldx16 % 8 ||
+            !aligned16(a->x16) || (reinterpret_cast<size_t>(a->row_partials) & 7))
+            return static_cast<int>(hipErrorInvalidValue);
+        p.x16 = a->x16;
+        p.ldx16 = a->ldx16;
+        p.partials = a->row_partials;
+    }
     p.stagger = a->stagger;
     p.sync1 = a->two_barriers ? 0 : 1;
     int variant = a->variant;
@@ -449,7 +466,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
 #endif
     const bool pp_ok = p.K >= 2 * TBK && a->epilogue >= 0 && a->epilogue <= VITHIP_BF16_EPI_F32_RESIDUAL &&
                        (size_t)p.lda * 2 * 256 < (1u << 31) && (size_t)p.ldw * 2 * 256 < (1u << 31);
-    if (variant >= 2 && !pp_ok) return static_cast<int>(hipErrorInvalidValue);
+    if ((variant >= 2 || ln_consumer || ln_producer) && (!pp_ok || variant == 1)) return static_cast<int>(hipErrorInvalidValue);
 #ifdef VIT_PROBES
     if (g_variant == 3) {
         if (!g_dbg) return static_cast<int>(hipErrorInvalidValue);

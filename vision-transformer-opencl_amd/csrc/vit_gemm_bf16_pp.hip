@@ -44,6 +44,9 @@ typedef unsigned short bf16_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+#ifndef PP_LNF_RS
+#define PP_LNF_RS 0
+#endif
 constexpr int PBM = 256, PBN = 256, PBK = 64;
 constexpr int PTHREADS = 512;
 constexpr int SLOT = 128 * 128;               // one half-tile: 128 rows x 64 bf16
@@ -90,10 +93,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
         }                                                                                               \
     } while (0)
 
+// Sum over the 8 lanes that share lane >> 3 (two quad steps and a mirror inside the half row): every lane ends with the total.
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    return v;
+}
+
 // DBG (timing-only builds, results wrong by construction): 1 = no LDS-DMA inside the K loop, 2 = no MFMA, 3 = no fragment reads, 4 = no epilogue.
-template <int EPI, int STAMP = 0, int DBG = 0>
+// LNF: the LayerNorm that follows (F32_RESIDUAL) or precedes (BF16, BF16_GELU) this GEMM is folded into it:
+//   producer  F32_RESIDUAL + LNF: besides C (fp32) the epilogue stores bf16(C) to p.x16 and, per row and 64-column strip
+//             of a wave, the partial (sum, sum of squares) of the fp32 values to p.partials -- vithip_rowstats_finalize turns
+//             them into (rstd, mean * rstd) per row;
+//   consumer  BF16 / BF16_GELU + LNF: A holds the UN-normalised bf16 rows, W the gamma-folded weight, bias the beta-folded
+//             bias, and the epilogue applies  v = rstd_m * acc - (mean * rstd)_m * colsum_n + bias_n  (= LN(x) . W^T + b).
+//             The tile's 256 row pairs and 256 column sums ride the LDS-DMA stream like the bias (waves 1..3).
+template <int EPI, int STAMP = 0, int DBG = 0, bool LNF = false>
 __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params p) {
-    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES + (STAMP == 2 ? 8 * 1024 : 0)];
+    static_assert(!(LNF && STAMP), "the event log and the LayerNorm slots share LDS");
+    constexpr int LN_OFF = LDS_BYTES;  // per tile parity: 1 KB column sums + 2 KB (rstd, mean*rstd) pairs
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES + (STAMP == 2 ? 8 * 1024 : 0) + (LNF ? 2 * 3072 : 0)];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wc = wave & 3;
@@ -155,21 +175,23 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     bool l_valid = true;
     __amdgpu_buffer_rsrc_t l_xr, l_wr, l_br;
     __amdgpu_buffer_rsrc_t n_xr, n_wr, n_br;  // descriptors of the cursor's NEXT tile, prepared ahead of the switch
-    auto tile_rsrc = [&](int tile, __amdgpu_buffer_rsrc_t &xr, __amdgpu_buffer_rsrc_t &wr, __amdgpu_buffer_rsrc_t &br) __attribute__((always_inline)) {
+    [[maybe_unused]] int l_m0 = 0, l_n0 = 0, n_m0 = 0, n_n0 = 0;  // LNF: origin of the cursor's tile and of its next tile
+    auto tile_rsrc = [&](int tile, __amdgpu_buffer_rsrc_t &xr, __amdgpu_buffer_rsrc_t &wr, __amdgpu_buffer_rsrc_t &br, int &m0o, int &n0o) __attribute__((always_inline)) {
         int tm, tn;
         tile_coords(tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
         const int m0 = tm * PBM, n0 = tn * PBN;
+        m0o = m0, n0o = n0;
         const int mrows = p.M - m0 < PBM ? p.M - m0 : PBM, nrows = p.N - n0 < PBN ? p.N - n0 : PBN;
         xr = make_rsrc(p.A + (size_t)m0 * p.lda, (unsigned)mrows * p.lda * 2);  // rows past M read as zero
         wr = make_rsrc(p.W + (size_t)n0 * p.ldw, (unsigned)nrows * p.ldw * 2);
         br = make_rsrc(p.bias + n0, (unsigned)nrows * 4);
     };
-    tile_rsrc(l_tile, l_xr, l_wr, l_br);
-    n_xr = l_xr, n_wr = l_wr, n_br = l_br;
+    tile_rsrc(l_tile, l_xr, l_wr, l_br, l_m0, l_n0);
+    n_xr = l_xr, n_wr = l_wr, n_br = l_br, n_m0 = l_m0, n_n0 = l_n0;
     // The tile switch costs two integer divisions (tile_coords); in a load section that was +700 cycles on the critical
     // path once per tile.  prepare_next() runs between the MFMAs of phase 1 of the last K step before the switch.
     auto prepare_next = [&]() __attribute__((always_inline)) {
-        if (l_kt == nk - 1 && l_tile + nwg < total) tile_rsrc(l_tile + nwg, n_xr, n_wr, n_br);
+        if (l_kt == nk - 1 && l_tile + nwg < total) tile_rsrc(l_tile + nwg, n_xr, n_wr, n_br, n_m0, n_n0);
     };
     auto advance = [&]() __attribute__((always_inline)) {
         if (++l_kt == nk) {
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             l_tile += nwg;
             l_tpar ^= 1;
             l_valid = l_tile < total;
-            l_xr = n_xr, l_wr = n_wr, l_br = n_br;
+            l_xr = n_xr, l_wr = n_wr, l_br = n_br, l_m0 = n_m0, l_n0 = n_n0;
         }
     };
     // issue half-tile KIND of the cursor's K step into the slot of K-step parity `parbit`
@@ -190,6 +212,20 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         if constexpr (KIND == 1) {
             if (l_kt == 0 && wave == 0)  // the tile's bias row: lanes 0..63 x 16 B = 256 floats
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(l_br, (lds_void *)(lds + BIAS_OFF + l_tpar * 1024), 16, lane * 16, 0, 0, 0);
+            if constexpr (LNF && !(EPI == VITHIP_BF16_EPI_F32_RESIDUAL || EPI == VITHIP_BF16_EPI_F32_EMBED)) {
+                if (l_kt == 0 && wave >= 1 && wave <= 3) {  // the tile's column sums (wave 1) and row pairs (waves 2, 3)
+                    char *ln = lds + LN_OFF + l_tpar * 3072;
+                    if (wave == 1) {
+                        const int nrows = p.N - l_n0 < PBN ? p.N - l_n0 : PBN;
+                        const __amdgpu_buffer_rsrc_t r = make_rsrc(p.ln_colsum + l_n0, (unsigned)nrows * 4);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)ln, 16, lane * 16, 0, 0, 0);
+                    } else {
+                        const int mrows = p.M - l_m0 < PBM ? p.M - l_m0 : PBM;  // rows past M read as zero: v = bias, never stored
+                        const __amdgpu_buffer_rsrc_t r = make_rsrc(p.ln_rows + (size_t)l_m0 * 2, (unsigned)mrows * 8);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)(ln + (wave - 1) * 1024), 16, (wave - 2) * 1024 + lane * 16, 0, 0, 0);
+                    }
+                }
+            }
         }
         if constexpr (KIND == 0 || KIND == 3) {
             constexpr int H = KIND == 3;
@@ -258,6 +294,20 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         for (int j = 0; j < 4; ++j)
             b4[j] = *reinterpret_cast<const f32x4 *>(lds + BIAS_OFF + e_tpar * 1024 +
                                                      (wc * 64 + (PAIRED ? 32 * (j >> 1) + 8 * l4 + 4 * (j & 1) : j * 16 + 4 * l4)) * 4);
+        [[maybe_unused]] f32x4 s4[4];  // LNF consumer: column sums of this lane's features, (rstd, mean*rstd) of its 8 tokens
+        [[maybe_unused]] f32x2 rs_all[8];
+        [[maybe_unused]] const char *ln_rows_lds = nullptr;  // + i * 128: this lane's (rstd, mean*rstd) pair of m-tile i
+        if constexpr (LNF && PAIRED) {
+            const char *ln = lds + LN_OFF + e_tpar * 3072;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s4[j] = *reinterpret_cast<const f32x4 *>(ln + (wc * 64 + 32 * (j >> 1) + 8 * l4 + 4 * (j & 1)) * 4);
+            ln_rows_lds = ln + 1024 + (g * 128 + l15) * 8;
+#if PP_LNF_RS == 1
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rs_all[i] = *reinterpret_cast<const f32x2 *>(ln_rows_lds + i * 128);
+#endif
+        }
         // Full-line accesses.  In registers a lane owns row (token) l15 and two 16-B chunks of it, so a plain store
         // instruction would write 16 rows x 64 B -- measured (tools/store_probe.py) at 14-19 B/clk per CU, against
         // 35-57 B/clk for 8 rows x 128 B with lane = 8 * row + chunk (the coalescer works on adjacent lanes).  Every
@@ -294,13 +344,24 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             // cycles per tile measured).  So they are inline asm with counted waits (vmcnt retires in issue order):
             // one block (2 loads) per batch, four batches in flight.  Counted waits need every load and store to be
             // issued, so only tiles fully inside the matrix take that path; edge tiles predicate and wait for all.
-            constexpr int NB = 16, AHEAD = EPI == VITHIP_BF16_EPI_F32_EMBED ? 2 : 4;  // pos_emb is cache-resident: short look-ahead, fewer registers
+            constexpr int NB = 16, AHEAD = EPI == VITHIP_BF16_EPI_F32_EMBED ? 2 : (LNF ? 2 : 4);  // pos_emb is cache-resident: short look-ahead, fewer registers
             f32x4 res[AHEAD][2];
             // running pointers (block order: (i, pj) = (0,0) (0,1) (1,0) ...; inside a block rows +0 and +8)
             const float *rbase = p.R + (size_t)(mw + row8) * p.ldr + nw + ch8 * 4;
             float *cbase = C + (size_t)(mw + row8) * p.ldc + nw + ch8 * 4;
             size_t roff = 0, coff = 0;
             const size_t r8 = (size_t)8 * p.ldr, c8 = (size_t)8 * p.ldc;
+            // LNF producer: bf16 copy of the new rows and per-row partial sums over this wave's 64 columns (strip 4*tn + wc)
+            [[maybe_unused]] bf16_t *xbase = nullptr;
+            [[maybe_unused]] float *pbase = nullptr;
+            [[maybe_unused]] size_t xoff = 0;
+            [[maybe_unused]] const size_t x8 = (size_t)8 * p.ldx16;
+            [[maybe_unused]] float ps_a = 0.f, pq_a = 0.f, ps_b = 0.f, pq_b = 0.f;
+            [[maybe_unused]] uint2 keep_a{0, 0}, keep_b{0, 0};
+            if constexpr (LNF) {
+                xbase = p.x16 + (size_t)(mw + row8) * p.ldx16 + nw + ch8 * 4;
+                pbase = p.partials + ((size_t)(tn * 4 + wc) * p.M + mw + row8) * 2;
+            }
             const int m_left = p.M - (mw + row8), n_left = p.N - (nw + ch8 * 4);
             auto in_range = [&](int blk, int ab) __attribute__((always_inline)) {
                 return (blk >> 1) * 16 + ab * 8 < m_left && (blk & 1) * 32 < n_left;
@@ -351,6 +412,10 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     asm volatile("" : "+v"(lcur.pp), "+v"(lcur.im));
                 }
             };
+            // (Tried: adding the residual IN the accumulator layout first -- 32 loads of 16 rows x 64 B, 8 in flight, nothing but loads
+            // in the queue -- and then transposing and storing the finished values, so that no load waits behind the stores of
+            // earlier blocks (vmcnt retires in issue order).  Same bits; out_proj 0.72 -> 0.76 ms, fc2 unchanged: the epilogue is not
+            // bound by that ordering but by its 512 KB through the 64-B/clk address path plus the LDS transposes.  Removed.)
             auto put_blk = [&](int blk) __attribute__((always_inline)) {
                 const int i = blk >> 1, pj = blk & 1;
                 put(blk, __builtin_bit_cast(u32x4, acc[i][2 * pj] + b4[2 * pj]), __builtin_bit_cast(u32x4, acc[i][2 * pj + 1] + b4[2 * pj + 1]));
@@ -369,16 +434,17 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     // block already stored since those loads were issued -> a constant 2 * (AHEAD - 1) + 2 * (AHEAD - 1)
                     // in steady state; simply wait for everything on edge tiles
                     if constexpr (INTERIOR) {
+                        // stores a block issues: 2 (C); LNF, odd blocks: + 2 (bf16 copy of the m-tile) + 2 (its row sums)
+                        auto stores_in = [](int b) constexpr { return 2 + ((LNF && (b & 1)) ? 4 : 0); };
                         const int younger_loads = 2 * ((blk + AHEAD - 1 < NB ? blk + AHEAD - 1 : NB - 1) - blk);
-                        const int younger_stores = 2 * (blk < AHEAD - 1 ? blk : AHEAD - 1);
+                        int younger_stores = 0;
+                        for (int b = blk - AHEAD + 1 > 0 ? blk - AHEAD + 1 : 0; b < blk; ++b) younger_stores += stores_in(b);
                         switch (younger_loads + younger_stores) {
-                            case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
-                            case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
-                            case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
-                            case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
-                            case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
-                            case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
-                            default: asm volatile("s_waitcnt vmcnt(12)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+#define PP_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
+                            PP_VMW(0) PP_VMW(2) PP_VMW(4) PP_VMW(6) PP_VMW(8) PP_VMW(10) PP_VMW(12) PP_VMW(14) PP_VMW(16)
+                            PP_VMW(18) PP_VMW(20) PP_VMW(22) PP_VMW(24) PP_VMW(26) PP_VMW(28) PP_VMW(30)
+#undef PP_VMW
+                            default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory"); break;
                         }
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(res[blk % AHEAD][0]), "+v"(res[blk % AHEAD][1])::"memory");
@@ -399,6 +465,54 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cb) = yb;
                     coff += (blk & 1) ? 2 * c8 - 32 : 32;
                     asm volatile("" : "+v"(coff));
+                    if constexpr (LNF) {
+                        const bool in_a = INTERIOR || in_range(blk, 0), in_b = INTERIOR || in_range(blk, 1);
+                        auto pk4 = [](f32x4 v) __attribute__((always_inline)) {
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                            return __builtin_bit_cast(uint2, o);
+                        };
+                        if constexpr (INTERIOR) {
+                            // 16-byte stores: lane pairs (ch8 even / odd) trade pieces so that the even lane owns 8 consecutive bf16 of
+                            // the m-tile's first 32-column block and the odd lane 8 of its second: per row 8 lanes x 16 B = one 128-B line
+                            const uint2 ca = pk4(ya), cb = pk4(yb);
+                            if ((blk & 1) == 0) {
+                                keep_a = ca, keep_b = cb;
+                            } else {
+                                const bool odd = ch8 & 1;
+                                auto swap2 = [](uint2 v) __attribute__((always_inline)) {
+                                    return uint2{(unsigned)__builtin_amdgcn_mov_dpp((int)v.x, 0xB1, 0xf, 0xf, true),
+                                                 (unsigned)__builtin_amdgcn_mov_dpp((int)v.y, 0xB1, 0xf, 0xf, true)};
+                                };
+                                const uint2 ra = swap2(odd ? keep_a : ca), rb = swap2(odd ? keep_b : cb);  // even lanes send their block-1 piece
+                                const u32x4 oa = odd ? u32x4{ra.x, ra.y, ca.x, ca.y} : u32x4{keep_a.x, keep_a.y, ra.x, ra.y};
+                                const u32x4 ob = odd ? u32x4{rb.x, rb.y, cb.x, cb.y} : u32x4{keep_b.x, keep_b.y, rb.x, rb.y};
+                                bf16_t *xd = xbase + xoff + (odd ? -4 : -32);  // xoff points at this row's second block here
+                                *reinterpret_cast<u32x4 *>(xd) = oa;
+                                *reinterpret_cast<u32x4 *>(xd + x8) = ob;
+                            }
+                        } else {
+                            if (in_a) *reinterpret_cast<uint2 *>(xbase + xoff) = pk4(ya);
+                            if (in_b) *reinterpret_cast<uint2 *>(xbase + xoff + x8) = pk4(yb);
+                        }
+                        xoff += (blk & 1) ? 2 * x8 - 32 : 32;
+                        asm volatile("" : "+v"(xoff));
+                        // columns outside N add nothing; rows outside M are summed but never stored
+                        const f32x4 za = in_a ? ya : f32x4{0.f, 0.f, 0.f, 0.f}, zb = in_b ? yb : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const float sa = (za[0] + za[1]) + (za[2] + za[3]), qa = (za[0] * za[0] + za[1] * za[1]) + (za[2] * za[2] + za[3] * za[3]);
+                        const float sb = (zb[0] + zb[1]) + (zb[2] + zb[3]), qb = (zb[0] * zb[0] + zb[1] * zb[1]) + (zb[2] * zb[2] + zb[3] * zb[3]);
+                        if ((blk & 1) == 0) {
+                            ps_a = sa, pq_a = qa, ps_b = sb, pq_b = qb;
+                        } else {  // both 32-column blocks of m-tile blk >> 1 are in: one (sum, sum of squares) pair per row
+                            const int i16 = (blk >> 1) * 16;
+                            const f32x2 ta = f32x2{sum8_dpp(ps_a + sa), sum8_dpp(pq_a + qa)}, tb = f32x2{sum8_dpp(ps_b + sb), sum8_dpp(pq_b + qb)};
+                            if (ch8 == 0) {
+                                if (INTERIOR || i16 < m_left) *reinterpret_cast<f32x2 *>(pbase + (size_t)i16 * 2) = ta;
+                                if (INTERIOR || i16 + 8 < m_left) *reinterpret_cast<f32x2 *>(pbase + (size_t)(i16 + 8) * 2) = tb;
+                            }
+                        }
+                    }
                     if (blk + 1 < NB) get(blk + 1, va, vb);
                     if (blk + AHEAD < NB) load_res(blk + AHEAD, interior_c);
                     __builtin_amdgcn_sched_barrier(0);  // keep the blocks apart: hoisting them together costs registers
@@ -416,12 +530,26 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             // Blocks: m-tile i = 16 rows x 64 bf16; paired mapping: accumulators (i, 2k), (i, 2k+1) of a lane are
             // features 32k + 8*l4 + [0,8), i.e. chunk 4k + l4.
             auto pack = [&](int i, u32x4 &c0, u32x4 &c1) __attribute__((always_inline)) {
+                [[maybe_unused]] f32x4 r4, m4;
+                if constexpr (LNF) {
+#if PP_LNF_RS == 1
+                    const f32x2 rs = rs_all[i];
+#else
+                    const f32x2 rs = *reinterpret_cast<const f32x2 *>(ln_rows_lds + i * 128);
+#endif
+                    r4 = f32x4{rs.x, rs.x, rs.x, rs.x}, m4 = f32x4{rs.y, rs.y, rs.y, rs.y};
+                }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     bf16x8 ob;
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        const f32x4 t4 = acc[i][2 * k + jj] + b4[2 * k + jj];
+                        f32x4 t4;
+                        if constexpr (LNF) {  // LN(x).W^T + b = rstd * (x.Wf^T) - mean*rstd * colsum + b'
+                            t4 = __builtin_elementwise_fma(acc[i][2 * k + jj], r4, b4[2 * k + jj] - m4 * s4[2 * k + jj]);
+                        } else {
+                            t4 = acc[i][2 * k + jj] + b4[2 * k + jj];
+                        }
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             f32x2 v = f32x2{t4[2 * h], t4[2 * h + 1]};
@@ -700,6 +828,15 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
 int launch_gemm_bf16_pp(hipStream_t s, const Bf16Params &p, int epilogue, int cus) {
     const int total = p.tiles_m * p.tiles_n;
     const dim3 grid(total < cus ? total : cus), block(PTHREADS);  // one persistent workgroup per CU
+    if (p.ln_rows || p.x16) {  // LayerNorm folded in (consumer: ln_rows + ln_colsum; producer: x16 + partials)
+        switch (epilogue) {
+            case VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 0, true>), grid, block, 0, s, p); break;
+            case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU, 0, 0, true>), grid, block, 0, s, p); break;
+            case VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL, 0, 0, true>), grid, block, 0, s, p); break;
+            default: return static_cast<int>(hipErrorInvalidValue);
+        }
+        return static_cast<int>(hipGetLastError());
+    }
     switch (epilogue) {
         case VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU>, grid, block, 0, s, p); break;

@@ -266,6 +266,12 @@ struct Bf16Params {
     int patches;              // F32_EMBED epilogue: patches per image
     int sync1;                // ping-pong kernel: 1 = one barrier per phase and wave (see PP_BARRIER_L/M)
     int stagger;              // ping-pong kernel: start-up skew between workgroups, in units of 512 cycles
+    // LayerNorm folded into the GEMMs either side of it (ping-pong kernel only; vithip_gemm_bf16_args has the contract):
+    const float *ln_rows;     // consumer (BF16 / BF16_GELU): [M][2] = (rstd, mean * rstd) of every row of A
+    const float *ln_colsum;   // consumer: [N] column sums of the gamma-folded weight
+    unsigned short *x16;      // producer (F32_RESIDUAL): bf16 copy of C, row stride ldx16
+    int ldx16;
+    float *partials;          // producer: [4 * tiles_n][M][2] partial (sum, sum of squares) per row and 64-column strip
 };
 int launch_gemm_bf16_pp(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);
 // vit_patch_embed_bf16.hip: patch embedding on the bf16 pipe as one implicit GEMM over the NCHW fp32 images

@@ -1,0 +1,175 @@
+// csrc/vit_lnfold.hip -- the small kernels around the LayerNorm fold of the bf16 forward (the fold itself lives in the
+// epilogues of csrc/vit_gemm_bf16_pp.hip; include/vit_hip_kernels.h states the algebra).
+//
+//   ln_fold_weights_kernel   once per weight upload: Wf = bf16(gamma * W), colsum = sum_k Wf, bias_f = bias + W . beta
+//   rowstats_bf16_kernel     first LayerNorm of the stack: x16 = bf16(x), rows = (rstd, mean*rstd)   (one wave per row, HBM-bound)
+//   rowstats_finalize_kernel per residual GEMM: strips x (sum, sum of squares) -> (rstd, mean*rstd), fixed summation order
+//
+// Statistics follow ViT_seq.c:103-121 as csrc/vit_rowops.hip does: var = E[x^2] - mean^2, 1/sqrtf((double)var + 1e-6).
+#include <hip/hip_runtime.h>
+
+#include "vit_hip_kernels.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ f32x2 finish(float s, float ss, int dim) {
+    const float mean = s / (float)dim;
+    const float var = ss / (float)dim - mean * mean;
+    const float inv_std = 1.0f / sqrtf((float)((double)var + 1e-6));
+    return f32x2{inv_std, mean * inv_std};
+}
+
+// one wave per output feature n
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float *__restrict__ W, const float *__restrict__ bias,
+                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                              unsigned short *__restrict__ Wf, float *__restrict__ colsum,
+                                                              float *__restrict__ bias_f, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (n >= N) return;  // wave-uniform
+    const float *src = W + (size_t)n * K;
+    unsigned short *dst = Wf + (size_t)n * K;
+    float cs = 0.f, bs = 0.f;
+    for (int c = lane * 4; c < K; c += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(src + c);
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + c);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (__bf16)(g[j] * w[j]);
+            cs += (float)o[j];
+            bs += b[j] * w[j];
+        }
+        *reinterpret_cast<bf16x4 *>(dst + c) = o;
+    }
+    cs = wave_sum(cs);
+    bs = wave_sum(bs);
+    if (lane == 0) {
+        colsum[n] = cs;
+        bias_f[n] = bias[n] + bs;
+    }
+}
+
+constexpr int RS_MAX_VEC = 8;  // float4 per lane: dim <= 2048
+template <int NVEC>
+__global__ __launch_bounds__(256) void rowstats_bf16_kernel(const float *__restrict__ x, size_t ldx, unsigned short *__restrict__ x16,
+                                                            size_t ldx16, float *__restrict__ rows_out, int rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * 256) >> 6;
+    for (int row = wave; row < rows; row += nwaves) {
+        const float *src = x + (size_t)row * ldx;
+        unsigned short *dst = x16 + (size_t)row * ldx16;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < dim) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(src + c);
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+                ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                *reinterpret_cast<bf16x4 *>(dst + c) = o;
+            }
+        }
+        s = wave_sum(s);
+        ss = wave_sum(ss);
+        if (lane == 0) *reinterpret_cast<f32x2 *>(rows_out + (size_t)row * 2) = finish(s, ss, dim);
+    }
+}
+
+__global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float *__restrict__ partials, int strips, int rows, int dim,
+                                                                float *__restrict__ rows_out) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.f, ss = 0.f;
+    for (int k = 0; k < strips; ++k) {  // strips in ascending column order, the same for every row and every launch
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(partials + ((size_t)k * rows + row) * 2);
+        s += v.x;
+        ss += v.y;
+    }
+    *reinterpret_cast<f32x2 *>(rows_out + (size_t)row * 2) = finish(s, ss, dim);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, size_t src_stride, float *__restrict__ dst,
+                                                          size_t dst_stride, int rows, int width) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * width) return;
+    const size_t r = i / width, c = i - r * width;
+    dst[r * dst_stride + c] = src[r * src_stride + c];
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int vithip_ln_strips(int N) { return N > 0 ? 4 * ((N + 255) / 256) : 0; }
+
+int vithip_ln_fold_weights(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
+                           unsigned short *Wf, float *colsum, float *bias_f, int N, int K) {
+    if (!W || !bias || !gamma || !beta || !Wf || !colsum || !bias_f || N <= 0 || K <= 0 || K % 4)
+        return static_cast<int>(hipErrorInvalidValue);
+    if (!aligned16(W) || !aligned16(gamma) || !aligned16(beta) || (reinterpret_cast<size_t>(Wf) & 7))
+        return static_cast<int>(hipErrorInvalidValue);
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), W, bias, gamma,
+                       beta, Wf, colsum, bias_f, N, K);
+    return static_cast<int>(hipGetLastError());
+}
+
+int vithip_rowstats_bf16(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *x16, size_t ldx16, float *rows_out,
+                         int rows, int dim) {
+    if (!x || !x16 || !rows_out || rows <= 0 || dim <= 0 || dim % 4 || dim > 64 * 4 * RS_MAX_VEC || ldx % 4 || ldx16 % 4 ||
+        ldx < (size_t)dim || ldx16 < (size_t)dim || !aligned16(x) || (reinterpret_cast<size_t>(x16) & 7) ||
+        (reinterpret_cast<size_t>(rows_out) & 7))
+        return static_cast<int>(hipErrorInvalidValue);
+    const int nvec = (dim + 255) / 256;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define RS_LAUNCH(NV) hipLaunchKernelGGL(rowstats_bf16_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ldx, x16, ldx16, rows_out, rows, dim)
+    switch (nvec) {
+        case 1: RS_LAUNCH(1); break;
+        case 2: RS_LAUNCH(2); break;
+        case 3: RS_LAUNCH(3); break;
+        case 4: RS_LAUNCH(4); break;
+        default: RS_LAUNCH(8); break;
+    }
+#undef RS_LAUNCH
+    return static_cast<int>(hipGetLastError());
+}
+
+int vithip_rowstats_finalize(vithip_stream_t stream, const float *partials, int strips, int rows, int dim, float *rows_out) {
+    if (!partials || !rows_out || strips <= 0 || rows <= 0 || dim <= 0 || (reinterpret_cast<size_t>(partials) & 7) ||
+        (reinterpret_cast<size_t>(rows_out) & 7))
+        return static_cast<int>(hipErrorInvalidValue);
+    hipLaunchKernelGGL(rowstats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
+                       strips, rows, dim, rows_out);
+    return static_cast<int>(hipGetLastError());
+}
+
+int vithip_gather_rows_f32(vithip_stream_t stream, const float *src, size_t src_stride, float *dst, size_t dst_stride, int rows,
+                           int width) {
+    if (!src || !dst || rows <= 0 || width <= 0 || src_stride < (size_t)width || dst_stride < (size_t)width)
+        return static_cast<int>(hipErrorInvalidValue);
+    const size_t total = (size_t)rows * width;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       src_stride, dst, dst_stride, rows, width);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // extern "C"

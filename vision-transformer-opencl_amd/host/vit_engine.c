@@ -41,6 +41,9 @@ struct vit_engine {
     size_t wblob_bytes;          /* bytes of it that carry data (the allocation has a read-only tail pad behind) */
     float **w;                   /* device pointer per weight index */
     unsigned short *wblob16;     /* the bf16 section inside wblob (dtype bf16 only) */
+    int fold;                    /* LayerNorm fold active (bf16 engines, vit_engine_options.ln_fold) */
+    unsigned short *wfold16;     /* per layer [gamma1-folded in_proj 3D x D | gamma2-folded fc1 H x D] (bf16) */
+    float *wfoldf;               /* per layer [colsum qkv 3D | bias qkv 3D | colsum fc1 H | bias fc1 H] */
     int lane_cap;                /* most images one lane may hold (32-bit buffer offsets of the fp32 kernels) */
     void *gemm_ws[VIT_MAX_LANES]; /* per lane (= per stream): vithip_gemm_args.workspace, zeroed once */
     /* use_graph: the captured forward and what it was captured for */
@@ -125,6 +128,7 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->prune_last_layer = 0;
     opt->use_graph = 0;
     opt->gemm_tile = 0;
+    opt->ln_fold = 0;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -145,6 +149,8 @@ static int fail(vit_engine *e, int code, const char *fmt, ...) {
 
 const char *vit_engine_last_error(const vit_engine *e) { return e ? e->err : "null engine"; }
 const vit_config *vit_engine_config(const vit_engine *e) { return &e->cfg; }
+
+#define WEIGHT_TAIL_PAD (1u << 20) /* GEMM loaders read (never use) up to a tile of rows past the last tensor */
 
 static int check_config(vit_engine *e) {
     const vit_config *c = &e->cfg;
@@ -214,6 +220,19 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
     HIP_TRY(e, vithip_malloc((void **)&e->logits, B * NC * sizeof(float)));
     if (e->opt.dtype == VIT_DTYPE_F32)
         for (int j = 0; j < VIT_MAX_LANES; ++j) HIP_TRY(e, vithip_gemm_f32_workspace_create(&e->gemm_ws[j]));
+    if (e->opt.dtype == VIT_DTYPE_BF16 && e->opt.ln_fold >= 0) {
+        /* the fold lives in the ping-pong GEMM (two K steps at least); its scratch (bf16 copy of x, row sums) uses the
+         * idle halves of the y and qkv allocations, which bf16 activations only half fill */
+        const int ok = e->cfg.embed_dim >= 128 && e->cfg.hidden_dim >= 128 && e->cfg.embed_dim % 64 == 0 && e->cfg.hidden_dim % 64 == 0;
+        if (!ok && e->opt.ln_fold > 0) return fail(e, VIT_ERR_ARG, "ln_fold needs embed_dim and hidden_dim >= 128 and multiples of 64");
+        e->fold = ok;
+        if (e->fold) {
+            const size_t L = (size_t)e->cfg.depth;
+            HIP_TRY(e, vithip_malloc((void **)&e->wfold16, L * (3 * D * D + H * D) * sizeof(unsigned short) + WEIGHT_TAIL_PAD));
+            HIP_TRY(e, vithip_memset((char *)e->wfold16 + L * (3 * D * D + H * D) * sizeof(unsigned short), 0, WEIGHT_TAIL_PAD, e->stream));
+            HIP_TRY(e, vithip_malloc((void **)&e->wfoldf, L * (6 * D + 2 * H) * sizeof(float)));
+        }
+    }
     HIP_TRY(e, vithip_stream_create(&e->copy_stream));
     for (int b = 0; b < 2; ++b) {
         HIP_TRY(e, vithip_malloc((void **)&e->in_stage[b], B * img * sizeof(float)));
@@ -254,6 +273,8 @@ void vit_engine_destroy(vit_engine *e) {
         if (e->ev_done[b]) vithip_event_destroy(e->ev_done[b]);
     }
     vithip_free(e->wblob);
+    vithip_free(e->wfold16);
+    vithip_free(e->wfoldf);
     free(e->w16);
     for (int j = 0; j < VIT_MAX_LANES - 1; ++j) {
         if (e->aux_stream[j]) { vithip_stream_sync(e->aux_stream[j]); vithip_stream_destroy(e->aux_stream[j]); }
@@ -289,8 +310,6 @@ static void drop_graph(vit_engine *e) {
     e->g_n = 0; e->g_images = NULL; e->g_probs = NULL; e->g_label = NULL; e->g_prob = NULL;
 }
 
-#define WEIGHT_TAIL_PAD (1u << 20) /* GEMM loaders read (never use) up to a tile of rows past the last tensor */
-
 /* (Re)allocate the device blob for this model and point w[] / w16[] into it (no data yet). */
 static int alloc_weight_blob(vit_engine *e, const size_t *off, size_t f32_floats, size_t gemm_floats) {
     const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
@@ -313,6 +332,21 @@ static int alloc_weight_blob(vit_engine *e, const size_t *off, size_t f32_floats
     return VIT_OK;
 }
 
+/* LayerNorm fold: Wf = bf16(gamma * W), column sums and beta-folded biases of every layer's in_proj (LN1) and fc1 (LN2), from
+ * the resident fp32 tensors.  Runs after every upload / replication; 2 launches per layer. */
+static int fold_ln_weights(vit_engine *e) {
+    if (!e->fold) return VIT_OK;
+    const size_t D = (size_t)e->cfg.embed_dim, H = (size_t)e->cfg.hidden_dim;
+    for (int l = 0; l < e->cfg.depth; ++l) {
+        float **lw = e->w + 4 + VIT_WEIGHTS_PER_LAYER * l;
+        unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);
+        float *ff = e->wfoldf + (size_t)l * (6 * D + 2 * H);
+        HIP_TRY(e, vithip_ln_fold_weights(e->stream, lw[2], lw[3], lw[0], lw[1], f16, ff, ff + 3 * D, (int)(3 * D), (int)D));
+        HIP_TRY(e, vithip_ln_fold_weights(e->stream, lw[8], lw[9], lw[6], lw[7], f16 + 3 * D * D, ff + 6 * D, ff + 6 * D + H, (int)H, (int)D));
+    }
+    return VIT_OK;
+}
+
 int vit_engine_load_weight_image(vit_engine *e, const vit_weight_image *img) {
     if (!e || !img || !img->f32) return e ? fail(e, VIT_ERR_ARG, "null weight image") : VIT_ERR_ARG;
     if (memcmp(&img->cfg, &e->cfg, sizeof(vit_config)) != 0 || img->count != e->n_weights)
@@ -325,6 +359,7 @@ int vit_engine_load_weight_image(vit_engine *e, const vit_weight_image *img) {
     HIP_TRY(e, vithip_memcpy_h2d(e->wblob, img->f32, up, e->stream));
     if (bf16 && !img->bf16_elems) /* image without a bf16 section: convert the GEMM-operand region on the device, one launch */
         HIP_TRY(e, vithip_f32_to_bf16(e->stream, e->wblob, e->wblob16, img->gemm_floats));
+    if ((rc = fold_ln_weights(e))) return rc;
     HIP_TRY(e, vithip_stream_sync(e->stream));
     e->weights_loaded = 1;
     return VIT_OK;
@@ -365,6 +400,7 @@ int vit_engine_copy_weights(vit_engine *dst, vit_engine *src) {
     /* device-to-device: on a multi-GPU node this crosses xGMI once per replica instead of PCIe (the in-process form of
      * "upload to GPU 0 + broadcast") */
     HIP_TRY(dst, vithip_memcpy_peer(dst->wblob, dst->opt.device, src->wblob, src->opt.device, dst->wblob_bytes, dst->stream));
+    if ((rc = fold_ln_weights(dst))) return rc; /* recomputed from the replica's own fp32 tensors: 2 launches per layer */
     HIP_TRY(dst, vithip_stream_sync(dst->stream));
     dst->weights_loaded = 1;
     return VIT_OK;
@@ -430,11 +466,41 @@ static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int
 static int gemm16(vit_engine *e, vithip_stream_t s, int stage, const unsigned short *A, int lda, const unsigned short *W,
                   const float *bias, const float *res, void *C, int ldc, int M, int N, int K, int epi) {
     vithip_gemm_bf16_args a;
+    memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
-    a.variant = 0; a.two_barriers = 0; a.stagger = 0;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_bf16(s, &a));
+    HIP_TRY(e, stage_end(e, s));
+    return VIT_OK;
+}
+
+/* The two GEMM roles of the LayerNorm fold (contiguous rows only).  Consumer: A = un-normalised bf16 rows, W / bias / colsum = the
+ * folded operands, rows = (rstd, mean*rstd) per row.  Producer: the residual GEMM also stores bf16(x) and the row sums, which
+ * one small launch turns into `rows` for the consumer behind it (accounted to the LayerNorm stage). */
+static int gemm16_ln(vit_engine *e, vithip_stream_t s, int stage, const unsigned short *A, int lda, const unsigned short *Wf,
+                     const float *bias_f, const float *colsum, const float *rows, unsigned short *C, int ldc, int M, int N, int K, int epi) {
+    vithip_gemm_bf16_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = Wf; a.ldw = K; a.bias = bias_f; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
+    a.ln_rows = rows; a.ln_colsum = colsum;
+    HIP_TRY(e, stage_begin(e, s, stage));
+    HIP_TRY(e, vithip_gemm_bf16(s, &a));
+    HIP_TRY(e, stage_end(e, s));
+    return VIT_OK;
+}
+static int gemm16_res_stats(vit_engine *e, vithip_stream_t s, int stage, const unsigned short *A, int lda, const unsigned short *W,
+                            const float *bias, float *x, unsigned short *x16, int ldx, float *partials, float *rows, int M, int N, int K) {
+    vithip_gemm_bf16_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = x; a.ldr = ldx; a.C = x; a.ldc = ldx;
+    a.M = M; a.N = N; a.K = K; a.epilogue = VITHIP_BF16_EPI_F32_RESIDUAL;
+    a.x16 = x16; a.ldx16 = ldx; a.row_partials = partials;
+    HIP_TRY(e, stage_begin(e, s, stage));
+    HIP_TRY(e, vithip_gemm_bf16(s, &a));
+    HIP_TRY(e, stage_end(e, s));
+    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
+    HIP_TRY(e, vithip_rowstats_finalize(s, partials, vithip_ln_strips(N), M, N, rows));
     HIP_TRY(e, stage_end(e, s));
     return VIT_OK;
 }
@@ -517,9 +583,84 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
     /* prune_last_layer: see vit_engine_options.  The class rows of a [n*T][D] buffer are rows 0, T, 2T, ... = a matrix
      * with leading dimension T*D, which every op here takes as it is. */
     const int prune = e->opt.prune_last_layer && T <= 224;
+    /* LayerNorm fold (e->fold): the bf16 copy of x lives in the idle half of the y allocation, the row sums and the
+     * (rstd, mean*rstd) pairs in the idle half of the qkv allocation; a lane uses its own rows of each. */
+    const int strips = vithip_ln_strips((int)D);
+    unsigned short *x16 = y16 + (size_t)e->opt.max_batch * T * D;
+    float *ln_part = (float *)(qkv16 + (size_t)e->opt.max_batch * T * 3 * D);
+    float *ln_rows = ln_part + (size_t)strips * e->opt.max_batch * T * 2;
+    float *cls_rows = ln_rows + (size_t)e->opt.max_batch * T * 2; /* pruned last layer: the pairs of the class rows, compact */
+#define PART(j) (ln_part + ROWS(j) * (size_t)strips * 2)
     for (int l = 0; l < c->depth && bf16; ++l) {
         float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
         unsigned short **lw16 = e->w16 + 4 + VIT_WEIGHTS_PER_LAYER * l;
+        const int last_pruned = prune && l == c->depth - 1;
+        if (e->fold) {
+            const unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);
+            const float *ff = e->wfoldf + (size_t)l * (6 * D + 2 * H);
+            const int feeds_fold = l + 1 < c->depth; /* the next layer reads x16 / rows */
+            if (l == 0)
+                LANES { /* the only LayerNorm without a residual GEMM in front of it: one pass for bf16(x) and the row pairs */
+                    HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+                    HIP_TRY(e, vithip_rowstats_bf16(lane[j].s, e->x + ROWS(j) * D, (size_t)D, x16 + ROWS(j) * D, (size_t)D,
+                                                    ln_rows + ROWS(j) * 2, lane[j].n * T, D));
+                    HIP_TRY(e, stage_end(e, lane[j].s));
+                }
+            if (last_pruned) { /* the sequence of the LayerNorm-kernel branch below, in folded form: class rows = rows 0, T, 2T, ... */
+                LANES { /* K and V of every token (folded in_proj rows D..3D); Q of the class rows, whose (rstd, mean*rstd) pairs
+                         * are copied out of the per-token array first */
+                    float *cls = cls_rows + (size_t)lane[j].off * 2;
+                    if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_QKV, x16 + ROWS(j) * D, D, f16 + (size_t)D * D, ff + 3 * D + D, ff + D,
+                                        ln_rows + ROWS(j) * 2, qkv16 + ROWS(j) * 3 * D + D, 3 * D, lane[j].n * T, 2 * D, D,
+                                        VITHIP_BF16_EPI_BF16))) return rc;
+                    HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
+                    HIP_TRY(e, vithip_gather_rows_f32(lane[j].s, ln_rows + ROWS(j) * 2, (size_t)T * 2, cls, 2, lane[j].n, 2));
+                    HIP_TRY(e, stage_end(e, lane[j].s));
+                    if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_QKV, x16 + ROWS(j) * D, T * D, f16, ff + 3 * D, ff, cls,
+                                        qkv16 + ROWS(j) * 3 * D, T * 3 * D, lane[j].n, D, D, VITHIP_BF16_EPI_BF16))) return rc;
+                }
+                LANES {
+                    HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
+                    HIP_TRY(e, vithip_attention_bf16io_rows(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T,
+                                                            c->num_heads, 1));
+                    HIP_TRY(e, stage_end(e, lane[j].s));
+                }
+                LANES
+                    if ((rc = gemm16_res_stats(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, T * D, lw16[4], lw[5], e->x + ROWS(j) * D,
+                                               x16 + ROWS(j) * D, T * D, PART(j), cls_rows + (size_t)lane[j].off * 2, lane[j].n, D, D))) return rc;
+                LANES
+                    if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_FC1, x16 + ROWS(j) * D, T * D, f16 + 3 * D * D, ff + 6 * D + H, ff + 6 * D,
+                                        cls_rows + (size_t)lane[j].off * 2, h16 + ROWS(j) * H, H, lane[j].n, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
+                LANES
+                    if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
+                                     e->x + ROWS(j) * D, T * D, lane[j].n, D, H, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
+                break;
+            }
+            LANES /* LN1 + in_proj */
+                if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_QKV, x16 + ROWS(j) * D, D, f16, ff + 3 * D, ff, ln_rows + ROWS(j) * 2,
+                                    qkv16 + ROWS(j) * 3 * D, 3 * D, lane[j].n * T, 3 * D, D, VITHIP_BF16_EPI_BF16))) return rc;
+            LANES {
+                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
+                HIP_TRY(e, vithip_attention_bf16io(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T, c->num_heads));
+                HIP_TRY(e, stage_end(e, lane[j].s));
+            }
+            LANES /* out_proj + residual; bf16(x) and row sums for LN2 */
+                if ((rc = gemm16_res_stats(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, D, lw16[4], lw[5], e->x + ROWS(j) * D,
+                                           x16 + ROWS(j) * D, D, PART(j), ln_rows + ROWS(j) * 2, lane[j].n * T, D, D))) return rc;
+            LANES /* LN2 + fc1 + GELU */
+                if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_FC1, x16 + ROWS(j) * D, D, f16 + 3 * D * D, ff + 6 * D + H, ff + 6 * D,
+                                    ln_rows + ROWS(j) * 2, h16 + ROWS(j) * H, H, lane[j].n * T, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
+            LANES { /* fc2 + residual; bf16(x) and row sums for the next layer's LN1 */
+                if (feeds_fold)
+                    rc = gemm16_res_stats(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
+                                          x16 + ROWS(j) * D, D, PART(j), ln_rows + ROWS(j) * 2, lane[j].n * T, D, H);
+                else
+                    rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
+                                e->x + ROWS(j) * D, D, lane[j].n * T, D, H, VITHIP_BF16_EPI_F32_RESIDUAL);
+                if (rc) return rc;
+            }
+            continue;
+        }
         LANES {
             HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
             HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)D, y16 + ROWS(j) * D, (size_t)D,
@@ -663,6 +804,7 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
     }
 #undef LANES
 #undef ROWS
+#undef PART
     for (int j = 1; j < L; ++j) { /* join */
         HIP_TRY(e, vithip_event_record(e->ev_join[j - 1], lane[j].s));
         HIP_TRY(e, vithip_stream_wait_event(s, e->ev_join[j - 1]));
