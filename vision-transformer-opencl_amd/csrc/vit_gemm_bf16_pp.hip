@@ -344,7 +344,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             // cycles per tile measured).  So they are inline asm with counted waits (vmcnt retires in issue order):
             // one block (2 loads) per batch, four batches in flight.  Counted waits need every load and store to be
             // issued, so only tiles fully inside the matrix take that path; edge tiles predicate and wait for all.
-            constexpr int NB = 16, AHEAD = EPI == VITHIP_BF16_EPI_F32_EMBED ? 2 : (LNF ? 2 : 4);  // pos_emb is cache-resident: short look-ahead, fewer registers
+            constexpr int NB = 16, AHEAD = EPI == VITHIP_BF16_EPI_F32_EMBED ? 2 : 4;  // pos_emb is cache-resident: short look-ahead, fewer registers
             f32x4 res[AHEAD][2];
             // running pointers (block order: (i, pj) = (0,0) (0,1) (1,0) ...; inside a block rows +0 and +8)
             const float *rbase = p.R + (size_t)(mw + row8) * p.ldr + nw + ch8 * 4;
@@ -352,16 +352,29 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
             size_t roff = 0, coff = 0;
             const size_t r8 = (size_t)8 * p.ldr, c8 = (size_t)8 * p.ldc;
             // LNF producer: bf16 copy of the new rows and per-row partial sums over this wave's 64 columns (strip 4*tn + wc)
-            [[maybe_unused]] bf16_t *xbase = nullptr;
-            [[maybe_unused]] float *pbase = nullptr;
-            [[maybe_unused]] size_t xoff = 0;
-            [[maybe_unused]] const size_t x8 = (size_t)8 * p.ldx16;
             [[maybe_unused]] float ps_a = 0.f, pq_a = 0.f, ps_b = 0.f, pq_b = 0.f;
             [[maybe_unused]] uint2 keep_a{0, 0}, keep_b{0, 0};
+            // The residual epilogue addresses memory as (wave-uniform 64-bit base in SGPRs) + (one 32-bit byte offset per lane): the
+            // block (m-tile, column pair) and the +8 row step move the SCALAR base, so a lane keeps one register per stream instead of
+            // pointer, running offset and row step (6): that is what lets the look-ahead stay 4 blocks deep with the fold's extra
+            // stores.  F32_EMBED keeps pointers (its rows are re-mapped per image).
+            constexpr bool SADDR = EPI == VITHIP_BF16_EPI_F32_RESIDUAL;
+            [[maybe_unused]] const char *r_s = reinterpret_cast<const char *>(p.R + (size_t)mw * p.ldr + nw);
+            [[maybe_unused]] char *c_s = reinterpret_cast<char *>(C + (size_t)mw * p.ldc + nw);
+            [[maybe_unused]] const unsigned r_l = (unsigned)(row8 * p.ldr + ch8 * 4) * 4u, c_l = (unsigned)(row8 * p.ldc + ch8 * 4) * 4u;
+            [[maybe_unused]] char *x_s = nullptr, *p_s = nullptr;
+            [[maybe_unused]] unsigned x_l = 0, x_lw = 0, p_l = 0;
             if constexpr (LNF) {
-                xbase = p.x16 + (size_t)(mw + row8) * p.ldx16 + nw + ch8 * 4;
-                pbase = p.partials + ((size_t)(tn * 4 + wc) * p.M + mw + row8) * 2;
+                x_s = reinterpret_cast<char *>(p.x16 + (size_t)mw * p.ldx16 + nw);
+                p_s = reinterpret_cast<char *>(p.partials + ((size_t)(tn * 4 + wc) * p.M + mw) * 2);
+                x_l = (unsigned)(row8 * p.ldx16 + ch8 * 4) * 2u;
+                x_lw = x_l + ((ch8 & 1) ? 56u : 0u);  // 16-byte stores: even lanes at their own place in block 0, odd lanes 4 elements back in block 1
+                p_l = (unsigned)row8 * 8u;
             }
+            // scalar byte offset of block blk (m-tile blk >> 1, column pair blk & 1) and of its +8 rows, for a row stride ld and an element size
+            auto blk_bytes = [](int blk, int ab, int ld, int esz) __attribute__((always_inline)) {
+                return ((size_t)((blk >> 1) * 16 + ab * 8) * ld + (blk & 1) * 32) * esz;
+            };
             const int m_left = p.M - (mw + row8), n_left = p.N - (nw + ch8 * 4);
             auto in_range = [&](int blk, int ab) __attribute__((always_inline)) {
                 return (blk >> 1) * 16 + ab * 8 < m_left && (blk & 1) * 32 < n_left;
@@ -396,7 +409,14 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                         const RowCursor c = ab ? step8(lcur) : lcur;
                         ptr = p.R + (size_t)(c.pp + 1) * p.ldr + nw + (blk & 1) * 32 + ch8 * 4;
                     }
-                    if constexpr (INTERIOR) {
+                    if constexpr (SADDR) {
+                        const char *sb = r_s + blk_bytes(blk, ab, p.ldr, 4);
+                        if constexpr (INTERIOR) {
+                            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(r) : "v"(r_l), "s"(sb) : "memory");
+                        } else if (in_range(blk, ab)) {
+                            asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(r) : "v"(r_l), "s"(sb) : "memory");
+                        }
+                    } else if constexpr (INTERIOR) {
                         // asynchronous: the value is only valid after the counted wait below.  Safe only in straight-line
                         // code (no predication, so no compiler-made copies of `r` before the data has arrived).
                         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(ptr) : "memory");
@@ -405,8 +425,10 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     }
                     res[blk % AHEAD][ab] = r;
                 }
-                roff += (blk & 1) ? 2 * r8 - 32 : 32;  // next block: other column pair, or the next m-tile
-                asm volatile("" : "+v"(roff));
+                if constexpr (!SADDR) {
+                    roff += (blk & 1) ? 2 * r8 - 32 : 32;  // next block: other column pair, or the next m-tile
+                    asm volatile("" : "+v"(roff));
+                }
                 if constexpr (EPI == VITHIP_BF16_EPI_F32_EMBED) {
                     if (blk & 1) lcur = step8(step8(lcur));
                     asm volatile("" : "+v"(lcur.pp), "+v"(lcur.im));
@@ -461,10 +483,17 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                         if (blk & 1) scur = step8(c1);
                         asm volatile("" : "+v"(scur.pp), "+v"(scur.im));
                     }
-                    if (INTERIOR || in_range(blk, 0)) *reinterpret_cast<f32x4 *>(ca) = ya;
-                    if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cb) = yb;
-                    coff += (blk & 1) ? 2 * c8 - 32 : 32;
-                    asm volatile("" : "+v"(coff));
+                    if constexpr (SADDR) {
+                        if (INTERIOR || in_range(blk, 0))
+                            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(c_l), "v"(ya), "s"(c_s + blk_bytes(blk, 0, p.ldc, 4)) : "memory");
+                        if (INTERIOR || in_range(blk, 1))
+                            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(c_l), "v"(yb), "s"(c_s + blk_bytes(blk, 1, p.ldc, 4)) : "memory");
+                    } else {
+                        if (INTERIOR || in_range(blk, 0)) *reinterpret_cast<f32x4 *>(ca) = ya;
+                        if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cb) = yb;
+                        coff += (blk & 1) ? 2 * c8 - 32 : 32;
+                        asm volatile("" : "+v"(coff));
+                    }
                     if constexpr (LNF) {
                         const bool in_a = INTERIOR || in_range(blk, 0), in_b = INTERIOR || in_range(blk, 1);
                         auto pk4 = [](f32x4 v) __attribute__((always_inline)) {
@@ -488,16 +517,13 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                                 const uint2 ra = swap2(odd ? keep_a : ca), rb = swap2(odd ? keep_b : cb);  // even lanes send their block-1 piece
                                 const u32x4 oa = odd ? u32x4{ra.x, ra.y, ca.x, ca.y} : u32x4{keep_a.x, keep_a.y, ra.x, ra.y};
                                 const u32x4 ob = odd ? u32x4{rb.x, rb.y, cb.x, cb.y} : u32x4{keep_b.x, keep_b.y, rb.x, rb.y};
-                                bf16_t *xd = xbase + xoff + (odd ? -4 : -32);  // xoff points at this row's second block here
-                                *reinterpret_cast<u32x4 *>(xd) = oa;
-                                *reinterpret_cast<u32x4 *>(xd + x8) = ob;
+                                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(x_lw), "v"(oa), "s"(x_s + blk_bytes(blk - 1, 0, p.ldx16, 2)) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(x_lw), "v"(ob), "s"(x_s + blk_bytes(blk - 1, 1, p.ldx16, 2)) : "memory");
                             }
                         } else {
-                            if (in_a) *reinterpret_cast<uint2 *>(xbase + xoff) = pk4(ya);
-                            if (in_b) *reinterpret_cast<uint2 *>(xbase + xoff + x8) = pk4(yb);
+                            if (in_a) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(x_l), "v"(pk4(ya)), "s"(x_s + blk_bytes(blk, 0, p.ldx16, 2)) : "memory");
+                            if (in_b) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(x_l), "v"(pk4(yb)), "s"(x_s + blk_bytes(blk, 1, p.ldx16, 2)) : "memory");
                         }
-                        xoff += (blk & 1) ? 2 * x8 - 32 : 32;
-                        asm volatile("" : "+v"(xoff));
                         // columns outside N add nothing; rows outside M are summed but never stored
                         const f32x4 za = in_a ? ya : f32x4{0.f, 0.f, 0.f, 0.f}, zb = in_b ? yb : f32x4{0.f, 0.f, 0.f, 0.f};
                         const float sa = (za[0] + za[1]) + (za[2] + za[3]), qa = (za[0] * za[0] + za[1] * za[1]) + (za[2] * za[2] + za[3] * za[3]);
@@ -508,8 +534,8 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                             const int i16 = (blk >> 1) * 16;
                             const f32x2 ta = f32x2{sum8_dpp(ps_a + sa), sum8_dpp(pq_a + qa)}, tb = f32x2{sum8_dpp(ps_b + sb), sum8_dpp(pq_b + qb)};
                             if (ch8 == 0) {
-                                if (INTERIOR || i16 < m_left) *reinterpret_cast<f32x2 *>(pbase + (size_t)i16 * 2) = ta;
-                                if (INTERIOR || i16 + 8 < m_left) *reinterpret_cast<f32x2 *>(pbase + (size_t)(i16 + 8) * 2) = tb;
+                                if (INTERIOR || i16 < m_left) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(p_l), "v"(ta), "s"(p_s + (size_t)i16 * 8) : "memory");
+                                if (INTERIOR || i16 + 8 < m_left) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(p_l), "v"(tb), "s"(p_s + (size_t)(i16 + 8) * 8) : "memory");
                             }
                         }
                     }
