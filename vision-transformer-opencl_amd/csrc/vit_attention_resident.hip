@@ -11,8 +11,8 @@
 // This version:
 //   * v_mfma_f32_16x16x4_f32 (exact fp32, same rate as 32x32x2): 16-row query blocks and 16-key tiles, so 197 tokens
 //     pad to 208 keys and the work splits into 13 half-size blocks that are dealt to the 8 waves so that every SIMD gets
-//     3 - 3.5 blocks: waves 0-3 take two blocks, waves 4-7 one, and the odd 13th block (the 5 tail rows) is cut in two by
-//     KEYS between waves 4 and 5, whose partial softmax results (running max, sum, O) meet in LDS and are merged by
+//     3.25 blocks: waves 0-3 take two blocks, waves 4-7 one, and the odd 13th block (the 5 tail rows) is cut in four by
+//     KEYS between waves 4-7, whose partial softmax results (running max, sum, O) meet in LDS and are merged by
 //     wave 4 in a fixed order (deterministic, no atomics);
 //   * persistent workgroups (one per CU) walk the (image, head) items and stage by LDS-DMA (buffer_load ... lds: no
 //     registers, zero-fill past the last token by the buffer bounds) in the OTHER phase's shadow:
@@ -64,8 +64,9 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
     // reads, 4 = waves 4-7 idle, 8 = no LDS-DMA after the first item
     // dbg != nullptr (probe build, tools/attn_probe.py): per wave 8 cycle stamps of the workgroup's SECOND item
     constexpr int KEYS = NKT * 16;
-    constexpr int KH = (NKT + 1) / 2;  // key tiles [0, KH) and [KH, NKT) of a tail block split between two waves
-    __shared__ __attribute__((aligned(1024))) char lds[2 * KEYS * ROWB + 2 * 16 * PART_LD * 4];
+    // a tail block is split by KEYS between four waves: key tiles [QB0, QB1), [QB1, QB2), [QB2, QB3), [QB3, NKT)
+    constexpr int QB1 = (NKT + 3) / 4, QB2 = (2 * NKT + 3) / 4, QB3 = (3 * NKT + 3) / 4;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * KEYS * ROWB + 4 * 16 * PART_LD * 4];
     char *const Ks = lds;
     char *const Vs = lds + KEYS * ROWB;
     float *const part = reinterpret_cast<float *>(lds + 2 * KEYS * ROWB);
@@ -80,13 +81,17 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
 
     // ---- which query blocks this wave owns (wave-uniform) -------------------------------------------------------
     const int nblk = (q_rows + 15) >> 4;
-    const bool split = nblk > RES_WAVES && (nblk & 1);  // odd block count: the last block is cut in two by keys
+    const bool split = nblk > RES_WAVES && (nblk & 1);  // odd block count: the last block is cut in four by keys
     const int nfull = split ? nblk - 1 : nblk;
     const bool hasA = wave < nfull && !((mode & 4) && wave >= 4), hasB = wave + RES_WAVES < nfull;
-    const int ta = nblk - 1 - RES_WAVES;  // waves ta, ta + 1 share the tail block (ta <= 5 as nblk <= 14)
-    const bool isTa = split && wave == ta, isTb = split && wave == ta + 1;
-    const int blkA = wave, blkB = (isTa || isTb) ? nblk - 1 : wave + RES_WAVES;
-    const bool has2 = hasB || isTa || isTb;
+    // Four one-block waves on four different SIMDs (SIMD = wave & 3) share the tail block, on the least loaded SIMDs: with 9 or 13
+    // blocks every SIMD carries the same number of full blocks (waves 4-7 take the quarters: 2.25 / 3.25 blocks per SIMD); with 11,
+    // waves 0 and 1 carry two blocks, so the quarters go to SIMDs 2 and 3 (waves 2, 3, 6, 7: 2.5 against 3).  Quarter 0 merges.
+    const int tq = !split ? -1
+                 : nblk == 11 ? (wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : -1)
+                              : (wave >= 4 ? wave - 4 : -1);
+    const int blkA = wave, blkB = tq >= 0 ? nblk - 1 : wave + RES_WAVES;
+    const bool has2 = hasB || tq >= 0;
 
     // ---- LDS-DMA of one head's K or V: 4 rows (1 KB) per wave instruction, rows past the last token read as zero ---
     const int row_in = lane >> 4, cpos = lane & 15;
@@ -255,60 +260,71 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
         }
         if (g == 0) { p[64] = m; p[65] = l; }
     };
-    // the two halves of a tail block, merged in a fixed order: O = (O0 a0 + O1 a1) / (l0 a0 + l1 a1), a = 2^((m - M) c)
+    // the four quarters of a tail block, merged in a fixed order: O = sum_k O_k a_k / sum_k l_k a_k, a_k = 2^((m_k - M) c)
     auto merge_tail = [&](int item) __attribute__((always_inline)) {
-        const float *p0 = part + n * PART_LD, *p1 = part + (16 + n) * PART_LD;
-        const float m0 = p0[64], l0 = p0[65], m1 = p1[64], l1 = p1[65];
-        const float M = fmaxf(m0, m1);
-        const float a0 = __builtin_amdgcn_exp2f((m0 - M) * kScale), a1 = __builtin_amdgcn_exp2f((m1 - M) * kScale);
-        const float inv = 1.0f / (l0 * a0 + l1 * a1);
+        const float *pk[4];
+        float a[4], M = -INFINITY, den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pk[k] = part + (k * 16 + n) * PART_LD;
+            M = fmaxf(M, pk[k][64]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = __builtin_amdgcn_exp2f((pk[k][64] - M) * kScale);
+            den += pk[k][65] * a[k];
+        }
+        const float inv = 1.0f / den;
         const int row = (nblk - 1) * 16 + n;
         if (row < q_rows) {
             const int img = item / heads, head = item - img * heads;
             float *dst = out + ((size_t)img * tokens + row) * D + head * HD + 16 * g;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const f32x4 u = *reinterpret_cast<const f32x4 *>(p0 + 16 * g + 4 * i);
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(p1 + 16 * g + 4 * i);
-                f32x4 w;
+                f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) w[q] = (u[q] * a0 + v[q] * a1) * inv;
-                *reinterpret_cast<f32x4 *>(dst + 4 * i) = w;
+                for (int k = 0; k < 4; ++k) w += *reinterpret_cast<const f32x4 *>(pk[k] + 16 * g + 4 * i) * a[k];
+                *reinterpret_cast<f32x4 *>(dst + 4 * i) = w * inv;
             }
         }
     };
 
     using std::integral_constant;
     constexpr integral_constant<int, 0> c0{};
-    constexpr integral_constant<int, KH> ch{};
+    constexpr integral_constant<int, QB1> q1{};
+    constexpr integral_constant<int, QB2> q2{};
+    constexpr integral_constant<int, QB3> q3{};
     constexpr integral_constant<int, NKT> cn{};
 
     // ---- persistent walk over the (image, head) items ----------------------------------------------------------------
     int item = blockIdx.x;
     const int step = gridDim.x;
     if (item >= n_items) return;  // workgroup-uniform
-    // LDS-DMA is issued by the two waves with the least matrix work (one block each when there are 9+ blocks): an issue
-    // costs 60-185 cycles of the issuing wave (MI355X_MICROARCH.md) and the others are on the phase's critical path
-    const bool dma_wave = wave >= RES_WAVES - 2;
-    const int w0 = wave & 1;                       // this DMA wave takes the 4-row groups t = 2k + w0
-    constexpr int DMA_PER_WAVE = (NKT * 4 + 1) / 2;
-    // Per-lane source offsets of a group are (t & 3)-periodic apart from the group's row base, which goes into the
-    // instruction's scalar offset: two VGPRs for K (t & 3 = w0, 2 + w0), one for V.  Rows past the last token are not
-    // zero-filled here but CLAMPED to the last token (its values are finite, the keys are masked / weigh 0): no bounds
-    // check involved, and only the last groups pay per-lane arithmetic.
+    // LDS-DMA is issued by the one-block waves among 4-7 -- all four up to 13 blocks, waves 6 and 7 with 14 (waves 4, 5 then
+    // carry two blocks and run the other role): an issue costs 60-185 cycles of the issuing wave (MI355X_MICROARCH.md), and
+    // the two-block waves are on the phase's critical path.
+    const bool dma4 = nfull <= 12;                 // workgroup-uniform
+    const bool dma_wave = wave >= (dma4 ? RES_WAVES - 4 : RES_WAVES - 2);
+    // A DMA wave takes the 4-row groups t = ND k + w0.  Per-lane source offsets of a group are (t & 3)-periodic apart from the
+    // group's row base, which goes into the instruction's scalar offset: one VGPR for K with four DMA waves (t & 3 = w0), two
+    // with two (t & 3 = w0, 2 + w0), one for V.  Rows past the last token are not zero-filled here but CLAMPED to the last
+    // token (its values are finite, the keys are masked / weigh 0): no bounds check involved, and only the last groups pay
+    // per-lane arithmetic.
+    const int w0 = dma4 ? (wave & 3) : (wave & 1);
     const int lane_row = row_in * ld * 4;
-    const int koffA = lane_row + ((cpos ^ ((w0) << 2 | row_in)) << 4);
+    const int koffA = lane_row + ((cpos ^ (w0 << 2 | row_in)) << 4);
     const int koffB = lane_row + ((cpos ^ ((2 + w0) << 2 | row_in)) << 4);
     const int voffV = lane_row + (cpos << 4);
-    auto dma2 = [&](const float *head_base, char *dst, bool swizzle) __attribute__((always_inline)) {
+    auto dma_nd = [&](auto nd_c, const float *head_base, char *dst, bool swizzle) __attribute__((always_inline)) {
+        constexpr int ND = decltype(nd_c)::value;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < DMA_PER_WAVE; ++k) {
-            const int t = 2 * k + w0;  // 4-row group
+        for (int k = 0; k < (NKT * 4 + ND - 1) / ND; ++k) {
+            const int t = ND * k + w0;  // 4-row group
             if (t < NKT * 4) {
                 // tokens > 16 (NKT - 1): only the groups of the LAST key tile can reach past the last token
-                if (2 * k + 1 < 4 * (NKT - 1) || 4 * t + 3 < tk) {  // first part known at compile time; wave-uniform
-                    const int voff = swizzle ? ((k & 1) ? koffB : koffA) : voffV;
+                if (ND * k + ND - 1 < 4 * (NKT - 1) || 4 * t + 3 < tk) {  // first part known at compile time; wave-uniform
+                    const int voff = swizzle ? ((ND == 2 && (k & 1)) ? koffB : koffA) : voffV;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + t * 1024), 16, voff, t * 16 * ld, 0, 0);
                 } else {
                     const int lrow = 4 * t + row_in;
@@ -318,6 +334,10 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
                 }
             }
         }
+    };
+    auto dma2 = [&](const float *head_base, char *dst, bool swizzle) __attribute__((always_inline)) {
+        if (dma4) dma_nd(integral_constant<int, 4>{}, head_base, dst, swizzle);
+        else dma_nd(integral_constant<int, 2>{}, head_base, dst, swizzle);
     };
 
     constexpr integral_constant<int, 1> one{};
@@ -387,7 +407,7 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             dma(base + D, Ks, true);
         }
         __syncthreads();
-        int tail_item = -1;  // wave ta: an item whose tail partials wait in LDS
+        int tail_item = -1;  // the wave with quarter 0: an item whose tail partials wait in LDS
         int iter = 0;
         for (;;) {
             asm volatile("" : "+s"(tk));
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             // ---- phase 1: scores + softmax (reads K); V(item) lands meanwhile
             const float *base = item_base(item);
             if (dma_wave && (!(mode & 8) || iter == 0)) dma2(base + 2 * D, Vs, false);
-            if (tail_item >= 0) {  // only wave ta
+            if (tail_item >= 0) {  // only the wave with quarter 0
                 merge_tail(tail_item);
                 tail_item = -1;
             }
@@ -406,8 +426,11 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
                 softmax(c0, cn, st[0], mA, lA);
             }
             RES_STAMP(1);
-            if (isTa) { s_mm(one, one, c0, ch, qf, st); softmax(c0, ch, st[1], mB, lB); }  // the tail block's keys [0, KH)
-            else if (isTb) { s_mm(one, one, ch, cn, qf, st); softmax(ch, cn, st[1], mB, lB); }  // ... [KH, NKT)
+            // this wave's quarter of the tail block's keys (wave-uniform)
+            if (tq == 0) { s_mm(one, one, c0, q1, qf, st); softmax(c0, q1, st[1], mB, lB); }
+            else if (tq == 1) { s_mm(one, one, q1, q2, qf, st); softmax(q1, q2, st[1], mB, lB); }
+            else if (tq == 2) { s_mm(one, one, q2, q3, qf, st); softmax(q2, q3, st[1], mB, lB); }
+            else if (tq == 3) { s_mm(one, one, q3, cn, qf, st); softmax(q3, cn, st[1], mB, lB); }
             RES_STAMP(2);
             __syncthreads();
             RES_STAMP(3);
@@ -425,13 +448,19 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
                 store_rows(item, blkA, o[0], 1.0f / lA);
             }
             RES_STAMP(4);
-            if (isTa) {
-                pv_mm(one, one, c0, ch, st, o);
+            if (tq == 0) {
+                pv_mm(one, one, c0, q1, st, o);
                 write_partial(0, o[1], mB, lB);
-                tail_item = item;
-            } else if (isTb) {
-                pv_mm(one, one, ch, cn, st, o);
+                tail_item = item;  // this wave merges the four partials after the next barrier
+            } else if (tq == 1) {
+                pv_mm(one, one, q1, q2, st, o);
                 write_partial(1, o[1], mB, lB);
+            } else if (tq == 2) {
+                pv_mm(one, one, q2, q3, st, o);
+                write_partial(2, o[1], mB, lB);
+            } else if (tq == 3) {
+                pv_mm(one, one, q3, cn, st, o);
+                write_partial(3, o[1], mB, lB);
             }
             RES_STAMP(5);
             __syncthreads();  // V is dead, the partials are visible, K/Q of the next item have landed
