@@ -106,23 +106,25 @@ __device__ __forceinline__ void gelu_erf_x8(float (&y)[8]) {
     }
 }
 
-// GELU for a bf16 destination, two values per instruction (v_pk_fma_f32 / v_pk_mul_f32).
-//   gelu(y) = max(y, 0) - h(|y|),   h = 0.5 |y| erfc(|y|/sqrt2) = t * exp2(Q(t)),  t = min(|y|/sqrt2, 4),
-//   Q(t) = log2(erfc(t)) - 1/2 as a degree-6 polynomial (max |dQ| 4.6e-5 on [0,4]).
+// GELU for a bf16 destination, two values per instruction (v_pk_fma_f32).
+//   gelu(y) = max(y, 0) - h(|y|),   h = 0.5 |y| erfc(|y|/sqrt2) = t * exp2(Q(t)),  t = min(|y|, 4 sqrt2),
+//   Q(t) = log2(erfc(t/sqrt2)) - 1 as a degree-6 polynomial in |y| itself (the fit on [0,4] of erfc's argument with the
+//   powers of 1/sqrt2 folded into the coefficients: no scaling multiply, and |y| is a source modifier of the v_min).
 // Max abs error 4.7e-6, at most 4.4 % of half a bf16 ulp of the result anywhere: invisible after the bf16
-// rounding that follows, at 9 VALU instructions per value instead of 19 for the fp32-accurate form above
+// rounding that follows, at 6.5 VALU instructions per value (6 + 1 v_pk_fma_f32, v_min, v_max, v_exp_f32 per pair and
+// value) instead of 19 for the fp32-accurate form above
 // (ViT_seq.c:231-233 is the fp32 definition; the bf16 path's parity bar is in tests/test_gpu_bf16.py).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_bf16_x2(f32x2 y) {
-    const f32x2 a = __builtin_elementwise_abs(y);
-    const f32x2 t = __builtin_elementwise_min(a * 0.70710678118654752440f, f32x2{4.0f, 4.0f});
-    constexpr float c[7] = {-0.5000373721122742f, -1.6270873546600342f, -0.9210273623466492f, -0.146488219499588f,
-                            0.02965814433991909f, -0.0036625200882554054f, 0.00020194612443447113f};
+    constexpr float kClamp = 5.656854249492381f;  // 4 sqrt2
+    const f32x2 t = f32x2{fminf(__builtin_fabsf(y.x), kClamp), fminf(__builtin_fabsf(y.y), kClamp)};
+    constexpr float c[7] = {-1.000037431716919f,   -1.1505244970321655f,   -0.4605136811733246f,  -0.05179140716791153f,
+                            0.007414536084979773f, -0.0006474481779150665f, 2.524326555430889e-05f};
     f32x2 q = f32x2{c[6], c[6]};
 #pragma unroll
     for (int k = 5; k >= 0; --k) q = __builtin_elementwise_fma(q, t, f32x2{c[k], c[k]});
     const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
-    return __builtin_elementwise_max(y, f32x2{0.f, 0.f}) - t * e;
+    return __builtin_elementwise_fma(-t, e, __builtin_elementwise_max(y, f32x2{0.f, 0.f}));
 }
 
 // Workgroup id -> tile id such that ids sharing an XCD (id % 8) get consecutive tiles.
