@@ -210,6 +210,17 @@ def test_ln_fold_is_invariant_to_lanes_chunks_and_pruning():
     assert (outs["kernels"].argmax(1) == outs["base"].argmax(1)).all()
 
 
+def test_ln_fold_option_is_validated():
+    """ln_fold = 1 insists on the fold and fails loudly where the ping-pong GEMM cannot carry it (embed_dim < 128); 0 (auto) falls
+    back to LayerNorm kernels there, and fp32 engines ignore the option (their path keeps the reference's operation order)."""
+    narrow = synth.ModelConfig(img_size=32, num_classes=10, embed_dim=64, depth=1, num_heads=1, hidden_dim=128)
+    with pytest.raises(B.VitError, match="ln_fold"):
+        B.Engine(narrow, max_batch=2, dtype="bf16", ln_fold=1)
+    for kw in (dict(dtype="bf16", ln_fold=0), dict(dtype="f32", ln_fold=1)):
+        eng = B.Engine(narrow, max_batch=2, **kw)
+        eng.close()
+
+
 def B_forward_reversed(cfg, W, imgs):
     eng = B.Engine(cfg, max_batch=16, dtype="bf16")
     eng.load_weights(W)
