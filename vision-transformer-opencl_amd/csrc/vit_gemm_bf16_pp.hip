@@ -868,6 +868,7 @@ int launch_gemm_bf16_pp(hipStream_t s, const Bf16Params &p, int epilogue, int cu
         case VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL>, grid, block, 0, s, p); break;
         case VITHIP_BF16_EPI_F32_EMBED: hipLaunchKernelGGL(gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_EMBED>, grid, block, 0, s, p); break;
+#ifdef VIT_PROBES  // timing-only (DBG) and stamped / event-log (STAMP) instantiations: probe build only
         case 201: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 1>), grid, block, 0, s, p); break;
         case 202: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 2>), grid, block, 0, s, p); break;
         case 203: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 0, 3>), grid, block, 0, s, p); break;
@@ -877,6 +878,7 @@ int launch_gemm_bf16_pp(hipStream_t s, const Bf16Params &p, int epilogue, int cu
         case 100 + VITHIP_BF16_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16, 1>), grid, block, 0, s, p); break;
         case 100 + VITHIP_BF16_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_BF16_GELU, 1>), grid, block, 0, s, p); break;
         case 100 + VITHIP_BF16_EPI_F32_RESIDUAL: hipLaunchKernelGGL((gemm_bf16_pp_kernel<VITHIP_BF16_EPI_F32_RESIDUAL, 1>), grid, block, 0, s, p); break;
+#endif
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());
