@@ -98,7 +98,7 @@ typedef struct {
      * tile: 0 = auto (128x128 tile, K step 32: persistent walk for the bias and bias+GELU epilogues, one pipelined tile
      *   per workgroup for bias+residual; 128x64 tiles for small problems); classic loop: 1 = 128x128, 2 = 256x128,
      *   3 = 128x64, 4 = 128x128 K16, 5 = 128x64 K16; pipelined loop: 10 = 128x128, 6 = 128x128 K16, 7 = 256x128,
-     *   8 = 128x64, 11 = 64x64 (auto for problems that leave CUs idle); 9 = persistent 128x128.
+     *   8 = 128x64, 11 = 64x64, 12 = 32x32 on 16x16x4 MFMA (K % 128 == 0; auto for problems that leave CUs idle); 9 = persistent 128x128.
      * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default 8; 1 = plain N-fastest order). */
     int tile, group_m;
     /* optional scratch made by vithip_gemm_f32_workspace_create() (uncached device memory, flags zeroed) and then left to the

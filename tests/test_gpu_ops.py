@@ -70,15 +70,30 @@ def test_gemm_tile_variants(oracle, tile):
     close(B.gemm(A, W, b, tile=tile, group_m=1), oracle.linear(A, W, b))
 
 
+@pytest.mark.parametrize("M,N,K", [(197, 768, 768), (515, 200, 256), (1, 1000, 768), (33, 40, 128)])
+def test_gemm_latency_tile(oracle, M, N, K):
+    """Tile 12 (32x32 workgroup tiles, 16x16 per wave, K step 128; csrc/vit_gemm_latency.hip) against the oracle, all three
+    epilogues, ragged M and N, a single row."""
+    A, W, b, R = u(30, (M, K), 1.0), u(31, (N, K), 0.1), u(32, (N,), 0.1), u(33, (M, N), 2.0)
+    lin = oracle.linear(A, W, b)
+    close(B.gemm(A, W, b, tile=12), lin)
+    close(B.gemm(A, W, b, epilogue=B.EPI_BIAS_GELU, tile=12), oracle.gelu(lin))
+    close(B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL, tile=12), R + lin)
+    with pytest.raises(B.VitError):
+        B.gemm(A[:, :96].copy(), W[:, :96].copy(), b, tile=12)   # K % 128 != 0: the caller must pick another tile
+
+
 def test_gemm_tile_shapes_are_bit_identical():
-    """The engine picks tile shapes by problem size (64x64 for one image, 128x64, 128x128 persistent ...) and documents
-    that a row's result does not depend on how many rows it is computed with (batch position, lanes, prune_last_layer):
-    every output must sum its k in the same order with the same MFMA whatever the tile."""
+    """The engine picks tile shapes by problem size (32x32 latency tiles or 64x64 for one image, 128x64, 128x128 persistent ...)
+    and documents that a row's result does not depend on how many rows it is computed with (batch position, lanes,
+    prune_last_layer): every output must sum its k in the same order, one fp32 rounding per product, whatever the tile -- including
+    tile 12, whose v_mfma_f32_16x16x4_f32 adds four products per instruction where the others' 32x32x2 adds two
+    (tools/probes/mfma_order_probe.hip: both equal a chain of fused multiply-adds in k order)."""
     M, N, K = 333, 200, 768
     A, W, b, R = u(40, (M, K), 1.0), u(41, (N, K), 0.1), u(42, (N,), 0.1), u(43, (M, N), 2.0)
     for epi, res in ((B.EPI_BIAS, None), (B.EPI_BIAS_GELU, None), (B.EPI_BIAS_RESIDUAL, R)):
         ref = B.gemm(A, W, b, residual=res, epilogue=epi, tile=1)
-        for tile in (0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+        for tile in (0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
             assert np.array_equal(B.gemm(A, W, b, residual=res, epilogue=epi, tile=tile), ref), (epi, tile)
         assert np.array_equal(B.gemm(A[:7], W, b, residual=None if res is None else res[:7], epilogue=epi), ref[:7]), epi
 

@@ -387,6 +387,9 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
         case 8: return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
         case 10: return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);  // pipelined
         case 11: return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);    // one 32x32 accumulator per wave
+        case 12:  // latency tile: 16x16 per wave on 16x16x4 MFMA (vit_gemm_latency.hip)
+            if (p.K % 128) return static_cast<int>(hipErrorInvalidValue);
+            return vitgemm::launch_gemm_f32_latency(stream, p, epilogue);
         default: {
             // auto.  Large problems: the persistent walk wins where the epilogue is light on registers (bias, bias+GELU:
             // fc1 22.0 vs 23.0 ms per step); the residual epilogue needs 255 VGPRs there and is faster one tile per
@@ -399,6 +402,11 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
             // a workgroup, the time of a GEMM is one wave's K loop -- 2 accumulators x K/2 MFMAs of 64 cycles -- so 64x64
             // tiles (one 32x32 accumulator per wave) halve it and quadruple the workgroups: fc2 of one image 110 -> 50 us.
             // Every output still sums its k in the same order with the same instruction: results are bit-identical.
+            // Fewer than ~160 tiles of 64x64 (one image: QKV 144, out_proj and fc2 48; four images: out_proj / fc2 156): the chain of
+            // ONE 32x32 accumulator is the whole GEMM.  32x32 workgroup tiles on v_mfma_f32_16x16x4_f32 (vit_gemm_latency.hip)
+            // quadruple the waves and shorten the chain 2.3x, bit-identically: fc2 of one image 61 -> 27 us, out_proj 20 -> 11.
+            if (p.K % 128 == 0 && (long)((p.M + 63) / 64) * ((p.N + 63) / 64) < 160)
+                return vitgemm::launch_gemm_f32_latency(stream, p, epilogue);
             if ((long)((p.M + 127) / 128) * ((p.N + 63) / 64) < 256)
                 return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);
             if (epilogue == VITHIP_EPI_BIAS_RESIDUAL) {
@@ -487,7 +495,7 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.sk_ws = a->workspace;
     if (a->workspace && (reinterpret_cast<size_t>(a->workspace) & 15)) return static_cast<int>(hipErrorInvalidValue);
-    if (a->tile < 0 || a->tile > 11 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
+    if (a->tile < 0 || a->tile > 12 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
     return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue, a->tile, a->group_m);
 }
 
