@@ -83,6 +83,22 @@ def test_gemm_latency_tile(oracle, M, N, K):
         B.gemm(A[:, :96].copy(), W[:, :96].copy(), b, tile=12)   # K % 128 != 0: the caller must pick another tile
 
 
+def test_mfma_shapes_add_their_products_like_an_fma_chain(tmp_path):
+    """The fact the latency tile rests on, checked on the device in front of us: v_mfma_f32_32x32x2_f32, v_mfma_f32_16x16x4_f32
+    and a chain of v_fma_f32 over the same k order produce the same bits (tools/probes/mfma_order_probe.hip, K = 3072)."""
+    import json, os, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    src = os.path.join(os.path.dirname(__file__), "..", "tools", "probes", "mfma_order_probe.hip")
+    exe = str(tmp_path / "mfma_order_probe")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", src, "-o", exe], check=True, timeout=300)
+    out = subprocess.run([exe], check=True, timeout=60, capture_output=True, text=True).stdout
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rec["of"] == 1024
+    assert rec["differ_32x32x2_vs_16x16x4"] == 0 and rec["differ_32x32x2_vs_fma_chain"] == 0 and rec["differ_16x16x4_vs_fma_chain"] == 0, rec
+
+
 def test_gemm_tile_shapes_are_bit_identical():
     """The engine picks tile shapes by problem size (32x32 latency tiles or 64x64 for one image, 128x64, 128x128 persistent ...)
     and documents that a row's result does not depend on how many rows it is computed with (batch position, lanes,
