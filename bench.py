@@ -32,7 +32,7 @@ METRIC = "images/sec ViT-B/16 224² fp32 @batch256; % MFMA roofline; top-1 match
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA (16x the fp32 matrix rate), no sparsity
 STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it at the metric configuration (fp32, batch 256, one lane)
-    "qkv": "gemm_f32_nt_persistent_kernel<EPI_BIAS>", "head": "gemm_f32_nt_persistent_kernel<EPI_BIAS>",
+    "qkv": "gemm_f32_nt_persistent_kernel<EPI_BIAS>", "head": "gemm_f32_nt_latency_kernel",
     "fc1": "gemm_f32_nt_persistent_kernel<EPI_BIAS_GELU>",
     "outproj": "gemm_f32_nt_persistent_kernel<EPI_BIAS_RESIDUAL>", "fc2": "gemm_f32_nt_persistent_kernel<EPI_BIAS_RESIDUAL>",
     "attn": "attention_f32_resident_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
