@@ -83,6 +83,21 @@ def test_gemm_latency_tile(oracle, M, N, K):
         B.gemm(A[:, :96].copy(), W[:, :96].copy(), b, tile=12)   # K % 128 != 0: the caller must pick another tile
 
 
+@pytest.mark.parametrize("T", [197, 176, 224, 130])
+def test_attention_small_batch_split_is_bit_identical(T):
+    """With few (image, head) items the resident attention kernel cuts a head's query blocks over up to four workgroups (parts);
+    a row's arithmetic must not depend on that: one image alone (12 items: 4 parts) equals the same image inside a batch that
+    fills the chip (312 items: 1 part) bit for bit -- including the tail block, which is cut in four by keys either way."""
+    heads, n = 12, 26
+    qkv = u(70, (n * T, 3 * heads * 64), 1.5)
+    big = B.attention(qkv, n, T, heads)
+    for i in (0, 7, n - 1):
+        one = B.attention(qkv[i * T:(i + 1) * T].copy(), 1, T, heads)
+        assert np.array_equal(one, big[i * T:(i + 1) * T]), (T, i)
+    two = B.attention(qkv[3 * T:5 * T].copy(), 2, T, heads)
+    assert np.array_equal(two, big[3 * T:5 * T]), T
+
+
 def test_mfma_shapes_add_their_products_like_an_fma_chain(tmp_path):
     """The fact the latency tile rests on, checked on the device in front of us: v_mfma_f32_32x32x2_f32, v_mfma_f32_16x16x4_f32
     and a chain of v_fma_f32 over the same k order produce the same bits (tools/probes/mfma_order_probe.hip, K = 3072)."""

@@ -48,10 +48,12 @@ constexpr int RES_THREADS = RES_WAVES * 64;
 constexpr int PART_LD = 68;       // floats per query row of a tail partial: 64 x O, max, sum, pad
 constexpr float kScale = 0.125f * 1.4426950408889634f;  // (1 / sqrtf(64)) * log2(e): p = exp2(s*kScale - max*kScale)
 
-template <int NKT>  // 16-key tiles: tokens <= 16 * NKT
+// NKT 16-key tiles: tokens <= 16 * NKT.  PARTS: the small-batch instantiation that spreads a head over parts_arg workgroups
+// (a run-time `parts` costs the metric configuration 1 % in registers and spills: it gets its own code)
+template <int NKT, bool PARTS = false>
 __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(const float *__restrict__ qkv,
                                                                              float *__restrict__ out, int tokens, int heads,
-                                                                             int n_items, int q_rows
+                                                                             int n_items, int q_rows, int parts_arg
 #ifdef VIT_PROBES
                                                                              , unsigned long long *__restrict__ dbg, int mode
 #endif
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
     // mode (probe build only, else 0): timing experiments with WRONG results: 1 = no softmax arithmetic, 2 = no LDS fragment
     // reads, 4 = waves 4-7 idle, 8 = no LDS-DMA after the first item
     // dbg != nullptr (probe build, tools/attn_probe.py): per wave 8 cycle stamps of the workgroup's SECOND item
+    const int parts = PARTS ? parts_arg : 1;
     constexpr int KEYS = NKT * 16;
     // a tail block is split by KEYS between four waves: key tiles [QB0, QB1), [QB1, QB2), [QB2, QB3), [QB3, NKT)
     constexpr int QB1 = (NKT + 3) / 4, QB2 = (2 * NKT + 3) / 4, QB3 = (3 * NKT + 3) / 4;
@@ -83,15 +86,38 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
     const int nblk = (q_rows + 15) >> 4;
     const bool split = nblk > RES_WAVES && (nblk & 1);  // odd block count: the last block is cut in four by keys
     const int nfull = split ? nblk - 1 : nblk;
-    const bool hasA = wave < nfull && !((mode & 4) && wave >= 4), hasB = wave + RES_WAVES < nfull;
+    // `parts` > 1 (few items: small batches): a work id is (item, part) and a workgroup takes only the part's share of the full
+    // blocks -- per = ceil(nfull / parts) <= 8 of them, one per wave -- so that one head's query blocks spread over `parts` CUs
+    // instead of leaving most of the chip idle; every part stages the head's whole K and V.  The last part also owns the tail
+    // block, cut in four over its waves 4-7 exactly as below: a row's arithmetic does not depend on the split.
+    const int per = (nfull + parts - 1) / parts;
+    const bool hasB = parts == 1 && wave + RES_WAVES < nfull;  // two full blocks: only in the one-part walk
     // Four one-block waves on four different SIMDs (SIMD = wave & 3) share the tail block, on the least loaded SIMDs: with 9 or 13
     // blocks every SIMD carries the same number of full blocks (waves 4-7 take the quarters: 2.25 / 3.25 blocks per SIMD); with 11,
     // waves 0 and 1 carry two blocks, so the quarters go to SIMDs 2 and 3 (waves 2, 3, 6, 7: 2.5 against 3).  Quarter 0 merges.
-    const int tq = !split ? -1
+    struct Own { bool hasA, has2; int tq, blkA, blkB; };
+    auto own = [&](int w) __attribute__((always_inline)) {  // what this wave computes of work id w (wave-uniform)
+        Own o;
+        if (parts == 1) {
+            o.hasA = wave < nfull && !((mode & 4) && wave >= 4);
+            o.tq = !split ? -1
                  : nblk == 11 ? (wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : -1)
                               : (wave >= 4 ? wave - 4 : -1);
-    const int blkA = wave, blkB = tq >= 0 ? nblk - 1 : wave + RES_WAVES;
-    const bool has2 = hasB || tq >= 0;
+            o.blkA = wave;
+            o.blkB = o.tq >= 0 ? nblk - 1 : wave + RES_WAVES;
+        } else {
+            const int part = w % parts, b0 = part * per;
+            const int nloc = nfull - b0 < per ? nfull - b0 : per;  // may be <= 0 for a trailing part
+            o.hasA = wave < nloc;
+            o.tq = (split && part == parts - 1 && wave >= 4) ? wave - 4 : -1;
+            o.blkA = b0 + wave;
+            o.blkB = nblk - 1;
+        }
+        o.has2 = hasB || o.tq >= 0;
+        return o;
+    };
+    const Own own0 = own(blockIdx.x);
+    const int blkA = own0.blkA, blkB = own0.blkB;  // the two-block role (parts == 1): constant over the walk
 
     // ---- LDS-DMA of one head's K or V: 4 rows (1 KB) per wave instruction, rows past the last token read as zero ---
     const int row_in = lane >> 4, cpos = lane & 15;
@@ -111,7 +137,8 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             }
         }
     };
-    auto item_base = [&](int item) -> const float * {
+    auto item_base = [&](int w) -> const float * {  // w = work id = item * parts + part
+        const int item = w / parts;
         const int img = item / heads, head = item - img * heads;
         return qkv + (size_t)img * tokens * ld + head * HD;
     };
@@ -237,9 +264,10 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto store_rows = [&](int item, int blk, const f32x4 (&o)[4], float scale) __attribute__((always_inline)) {
+    auto store_rows = [&](int w, int blk, const f32x4 (&o)[4], float scale) __attribute__((always_inline)) {
         const int row = blk * 16 + n;
         if (row < q_rows) {
+            const int item = w / parts;
             const int img = item / heads, head = item - img * heads;
             float *dst = out + ((size_t)img * tokens + row) * D + head * HD + 16 * g;
 #pragma unroll
@@ -261,7 +289,8 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
         if (g == 0) { p[64] = m; p[65] = l; }
     };
     // the four quarters of a tail block, merged in a fixed order: O = sum_k O_k a_k / sum_k l_k a_k, a_k = 2^((m_k - M) c)
-    auto merge_tail = [&](int item) __attribute__((always_inline)) {
+    auto merge_tail = [&](int w) __attribute__((always_inline)) {
+        const int item = w / parts;
         const float *pk[4];
         float a[4], M = -INFINITY, den = 0.f;
 #pragma unroll
@@ -297,9 +326,10 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
     constexpr integral_constant<int, NKT> cn{};
 
     // ---- persistent walk over the (image, head) items ----------------------------------------------------------------
-    int item = blockIdx.x;
+    int item = blockIdx.x;  // work id (= item when parts == 1)
     const int step = gridDim.x;
-    if (item >= n_items) return;  // workgroup-uniform
+    const int n_work = n_items * parts;
+    if (item >= n_work) return;  // workgroup-uniform
     // LDS-DMA is issued by the one-block waves among 4-7 -- all four up to 13 blocks, waves 6 and 7 with 14 (waves 4, 5 then
     // carry two blocks and run the other role): an issue costs 60-185 cycles of the issuing wave (MI355X_MICROARCH.md), and
     // the two-block waves are on the phase's critical path.
@@ -382,7 +412,7 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             const int next = item + step;
             f32x4 o[2][4];
             pv_mm(two, c0, c0, cn, st, o);
-            if (next < n_items) {  // Q of the next item (this role is at the register limit until here)
+            if (next < n_work) {  // Q of the next item (this role is at the register limit until here)
                 const float *nb = item_base(next);
                 load_q(nb, blkA, qf[0]);
                 load_q(nb, blkB, qf[1]);
@@ -394,16 +424,17 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             __syncthreads();  // V is dead, K/Q of the next item have landed
             RES_STAMP(6);
             ++iter;
-            if (next >= n_items) break;
+            if (next >= n_work) break;
             item = next;
         }
     } else {
         // ============================ role: one block (or none), tail halves, LDS-DMA =================================
         f32x4 qf[2][4];
+        Own cur = own0;  // this wave's share of the current work id; with parts > 1 it changes from one to the next
         {
             const float *base = item_base(item);
-            if (hasA) load_q(base, blkA, qf[0]);
-            if (has2) load_q(base, blkB, qf[1]);
+            if (cur.hasA) load_q(base, cur.blkA, qf[0]);
+            if (cur.has2) load_q(base, cur.blkB, qf[1]);
             dma(base + D, Ks, true);
         }
         __syncthreads();
@@ -421,6 +452,8 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             }
             f32x4 st[2][NKT];
             float mA = 0.f, lA = 1.f, mB = 0.f, lB = 1.f;
+            const bool hasA = cur.hasA;
+            const int tq = cur.tq;
             if (hasA) {
                 s_mm(one, c0, c0, cn, qf, st);
                 softmax(c0, cn, st[0], mA, lA);
@@ -436,16 +469,18 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             RES_STAMP(3);
             // ---- phase 2: O = V^T . P^T (reads V); K and Q of the next item land meanwhile
             const int next = item + step;
-            if (next < n_items) {  // workgroup-uniform
+            Own nxt = cur;
+            if (next < n_work) {  // workgroup-uniform
                 const float *nb = item_base(next);
                 if (dma_wave && !(mode & 8)) dma2(nb + D, Ks, true);
-                if (hasA) load_q(nb, blkA, qf[0]);  // consumed after the barrier below
-                if (has2) load_q(nb, blkB, qf[1]);
+                nxt = own(next);
+                if (nxt.hasA) load_q(nb, nxt.blkA, qf[0]);  // consumed after the barrier below
+                if (nxt.has2) load_q(nb, nxt.blkB, qf[1]);
             }
             f32x4 o[2][4];
             if (hasA) {
                 pv_mm(one, c0, c0, cn, st, o);
-                store_rows(item, blkA, o[0], 1.0f / lA);
+                store_rows(item, cur.blkA, o[0], 1.0f / lA);
             }
             RES_STAMP(4);
             if (tq == 0) {
@@ -466,8 +501,9 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             __syncthreads();  // V is dead, the partials are visible, K/Q of the next item have landed
             RES_STAMP(6);
             ++iter;
-            if (next >= n_items) break;
+            if (next >= n_work) break;
             item = next;
+            cur = nxt;
         }
         if (tail_item >= 0) merge_tail(tail_item);
     }
@@ -489,12 +525,27 @@ int g_res_mode = 0;                       // vithip_attention_set_probe_mode
 template <int NKT>
 int launch_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows, int cus) {
     const int items = n_images * heads;
-    const int grid = items < cus ? items : cus;  // one workgroup per CU: the LDS holds one head
+    // Few items (small batches): cut every head's query blocks into `parts` shares for as many workgroups, while that still
+    // leaves a share at least two full blocks (one image: 12 heads x 4 parts instead of 12 workgroups on 256 CUs).
+    const int nblk = (q_rows + 15) / 16, nfull = (nblk > RES_WAVES && (nblk & 1)) ? nblk - 1 : nblk;
+    int parts = 1;
+    while (parts < 4 && items * (parts + 1) <= cus && (nfull + parts) / (parts + 1) >= 2) ++parts;
+    const int work = items * parts;
+    const int grid = work < cus ? work : cus;  // one workgroup per CU: the LDS holds one head
 #ifdef VIT_PROBES
-    hipLaunchKernelGGL(attention_f32_resident_kernel<NKT>, dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items, q_rows,
-                       g_res_dbg, g_res_mode);
+    if (parts > 1)
+        hipLaunchKernelGGL((attention_f32_resident_kernel<NKT, true>), dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items,
+                           q_rows, parts, g_res_dbg, g_res_mode);
+    else
+        hipLaunchKernelGGL((attention_f32_resident_kernel<NKT, false>), dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items,
+                           q_rows, 1, g_res_dbg, g_res_mode);
 #else
-    hipLaunchKernelGGL(attention_f32_resident_kernel<NKT>, dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items, q_rows);
+    if (parts > 1)
+        hipLaunchKernelGGL((attention_f32_resident_kernel<NKT, true>), dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items,
+                           q_rows, parts);
+    else
+        hipLaunchKernelGGL((attention_f32_resident_kernel<NKT, false>), dim3(grid), dim3(RES_THREADS), 0, s, qkv, out, tokens, heads, items,
+                           q_rows, 1);
 #endif
     return static_cast<int>(hipGetLastError());
 }
