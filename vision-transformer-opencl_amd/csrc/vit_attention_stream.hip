@@ -314,16 +314,27 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
         for (int b = 0; b < MAXB; ++b) {
             const int row = (wave + ST_WAVES * b) * 32 + r;
             const float inv = 1.0f / (l_run[b] + __shfl_xor(l_run[b], 32));  // all lanes take part in the exchange
-            if (wave + ST_WAVES * b < nblk && row < tokens) {
-                bf16_t *dst = out + ((size_t)img * tokens + row) * D + head * SHD + 4 * h;
+            if (wave + ST_WAVES * b < nblk) {  // wave-uniform: the half-wave exchange below needs every lane
+                // A lane holds d = 8g + 4h + (0..3) of its row per column group g: 8-byte pieces, and a row-per-lane store of
+                // those is issue-bound (16 instructions of 64 scattered 8-byte pieces per block).  v_permlane32_swap trades
+                // group g of the upper half-wave for group g + 1 of the lower one: afterwards lanes 0-31 own d = 8g..8g+7 and
+                // lanes 32-63 d = 8g+8..8g+15 of their rows -- one 16-byte store per pair of groups, half the instructions.
+                bf16_t *dst = out + ((size_t)img * tokens + row) * D + head * SHD + 8 * h;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        bf16x4 w;
+                    for (int g = 0; g < 4; g += 2) {
+                        bf16x4 w0, w1;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) w[q] = (__bf16)(o[b][dt][4 * g + q] * inv);
-                        *reinterpret_cast<bf16x4 *>(dst + dt * 32 + 8 * g) = w;
+                        for (int q = 0; q < 4; ++q) {
+                            w0[q] = (__bf16)(o[b][dt][4 * g + q] * inv);
+                            w1[q] = (__bf16)(o[b][dt][4 * (g + 1) + q] * inv);
+                        }
+                        uint2 a = __builtin_bit_cast(uint2, w0), c = __builtin_bit_cast(uint2, w1);
+                        auto sx = __builtin_amdgcn_permlane32_swap(a.x, c.x, false, false);
+                        auto sy = __builtin_amdgcn_permlane32_swap(a.y, c.y, false, false);
+                        const uint4 piece = {sx[0], sy[0], sx[1], sy[1]};  // lower half: [own g | upper's g]; upper: [lower's g+1 | own g+1]
+                        if (row < tokens) *reinterpret_cast<uint4 *>(dst + dt * 32 + 8 * g) = piece;
                     }
             }
         }
