@@ -435,6 +435,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_chunked_kernel(cons
 //     is key 16s + 8(j>>2) + 4h + (j&3) -- the V^T fragment is gathered in that same order.
 // Softmax, max and sums are fp32; P is rounded to bf16 once (the documented cost of the bf16 variant).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4s;
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4v lds_short4v;
 
@@ -586,19 +587,27 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
                 }
             }
 
-            if (q0 + r < q_rows) {
+            {
+                // 16-byte stores: v_permlane32_swap trades column group g of the upper half-wave for group g + 1 of the lower one,
+                // so lanes 0-31 own d = 8g..8g+7 and lanes 32-63 d = 8g+8..8g+15 of their rows (half the store instructions of the
+                // 8-byte row-per-lane form; the exchange needs every lane of the computing wave)
                 const int img = item / heads, head = item % heads;
-                bf16_t *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 4 * h;
+                bf16_t *dst = out + ((size_t)img * tokens + q0 + r) * D + head * HD + 8 * h;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 w;
-                        w[0] = o[dt][4 * g + 0] * inv;
-                        w[1] = o[dt][4 * g + 1] * inv;
-                        w[2] = o[dt][4 * g + 2] * inv;
-                        w[3] = o[dt][4 * g + 3] * inv;
-                        store4<bf16_t>(dst + dt * 32 + 8 * g, w);
+                    for (int g = 0; g < 4; g += 2) {
+                        bf16x4s w0, w1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            w0[q] = (__bf16)(o[dt][4 * g + q] * inv);
+                            w1[q] = (__bf16)(o[dt][4 * (g + 1) + q] * inv);
+                        }
+                        const uint2 a = __builtin_bit_cast(uint2, w0), c = __builtin_bit_cast(uint2, w1);
+                        auto sx = __builtin_amdgcn_permlane32_swap(a.x, c.x, false, false);
+                        auto sy = __builtin_amdgcn_permlane32_swap(a.y, c.y, false, false);
+                        const uint4 piece = {sx[0], sy[0], sx[1], sy[1]};
+                        if (q0 + r < q_rows) *reinterpret_cast<uint4 *>(dst + dt * 32 + 8 * g) = piece;
                     }
             }
         }
