@@ -131,6 +131,32 @@ def test_attention_bf16_io(oracle, n, T, heads, mfma):
         assert (np.abs(got[i] - ref) <= 2.0 ** -8 * np.abs(ref) + slack).all(), float(np.abs(got[i] - ref).max())
 
 
+@pytest.mark.parametrize("T", [577, 300])
+def test_attention_bf16_streamed_reference_maximum_moves(oracle, T):
+    """The streamed kernel (225..704 tokens) keeps a row's running maximum as a reference that moves only when the scores outgrow
+    it by more than 2^8: uniform random scores never do after the first sub-chunk, so this input makes them -- every row's score
+    rises along the keys (by 4..15 in the exponent per 64-key sub-chunk, every row at its own rate; the second head's fall instead) -- and
+    O, the row sum and the pending P must all be rescaled exactly once each time."""
+    heads, n = 2, 1
+    D = heads * 64
+    rng = np.random.default_rng(5)
+    j = np.arange(T, dtype=np.float32)[:, None] / T
+    rate = np.linspace(0.3, 1.0, T, dtype=np.float32)[:, None]                   # per query row
+    q = np.concatenate([rate * 2.0 * np.ones((T, 64), np.float32), -rate * 2.0 * np.ones((T, 64), np.float32)], axis=1)
+    k = np.concatenate([j * 6.0 * np.ones((T, 64), np.float32), j * 6.0 * np.ones((T, 64), np.float32)], axis=1)
+    q += rng.uniform(-0.05, 0.05, q.shape).astype(np.float32)
+    k += rng.uniform(-0.05, 0.05, k.shape).astype(np.float32)
+    v = rng.uniform(-1.5, 1.5, (T, D)).astype(np.float32)
+    bits = B.to_bf16_bits(np.concatenate([q, k, v], axis=1))
+    qkv = B.from_bf16_bits(bits)
+    got = B.from_bf16_bits(B.attention_bf16io(bits, n, T, heads)).reshape(T, D)
+    qq, kk, vv = (np.ascontiguousarray(qkv[:, i * D:(i + 1) * D]) for i in range(3))
+    ref = oracle.attention_core(qq, kk, vv, heads)
+    s0 = (qq[:, :64] @ kk[:, :64].T) * 0.125 * 1.4426950408889634                 # head 0: rising, head 1: falling
+    assert float((s0[:, -1] - s0[:, 63]).min()) > 24.0                            # the exponent really outgrows 2^8 several times
+    assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(np.abs(got - ref).max())
+
+
 BF16_PROB_TOL = 2e-2   # bf16 activations carry 8 significant bits; the fp32 bar (1e-4) does not apply here
 
 

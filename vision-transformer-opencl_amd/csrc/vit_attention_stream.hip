@@ -248,8 +248,13 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                 for (int v = 0; v < 16; v += 2) mx2 = __builtin_elementwise_max(mx2, f32x2{st[buf][u][v], st[buf][u][v + 1]});
             float cmax = fmaxf(mx2[0], mx2[1]);
             cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            // The running maximum is a REFERENCE, not a bound: it moves only when a row's scores outgrow it by more than
+            // kDefer in the exponent (T13 of the CDNA4 guide).  P then reaches 2^kDefer instead of 1 -- the same relative
+            // precision in bf16 and in the fp32 sums -- and the O-wide rescale below, which used to run in almost every
+            // sub-chunk (some row of 32 nearly always finds a slightly larger score), runs a few times per head.
+            constexpr float kDefer = 8.0f;
             const float m_old = m_run[b];
-            const float m_new = fmaxf(m_old, cmax);  // finite: the sub-chunk has at least one valid key
+            const float m_new = (cmax - m_old) * kScaleS > kDefer ? cmax : m_old;  // first sub-chunk: m_old = -inf -> cmax (finite)
             m_run[b] = m_new;
             const f32x2 sc2 = {kScaleS, kScaleS}, mxs2 = {-m_new * kScaleS, -m_new * kScaleS};
             f32x2 sum2 = {0.0f, 0.0f};
