@@ -53,6 +53,8 @@ typedef struct {
                       * "LayerNorm folding"): 0 = auto (on when embed_dim and hidden_dim >= 128), 1 = on (error when the
                       * shapes do not allow it), -1 = off (a LayerNorm kernel per LayerNorm).  Not used by fp32 engines:
                       * the fp32 path keeps the reference's operation order. */
+    int gemm_handover_test; /* testing: vithip_gemm_args.handover_test for every fp32 GEMM (1 = helper pieces arrive too late and
+                             * every owner computes its whole tile; results must not change) */
 } vit_engine_options;
 
 enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };
@@ -118,6 +120,13 @@ int vit_engine_sync(vit_engine *e);
  * pinned buffers; blocking.
  */
 int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, float *const *probs);
+
+/*
+ * The fp32 GEMMs' helper-piece hand-over (csrc/vit_gemm_persistent.hip) since the last call, summed over the lanes: tiles whose
+ * first K-steps came from a helper workgroup / tiles whose owner found no piece when it looked and computed all of it.  The
+ * second number is lost time, never a wrong result (nothing in the hand-over waits or gives up).  Synchronises the device.
+ */
+int vit_engine_handover_stats(vit_engine *e, long *taken, long *recomputed);
 
 /* Debug/test taps: copy the logits of the most recent chunk (rows = images of that chunk). */
 int vit_engine_read_logits(vit_engine *e, float *dst, int rows);

@@ -101,19 +101,24 @@ typedef struct {
      *   8 = 128x64, 11 = 64x64, 12 = 32x32 on 16x16x4 MFMA (K % 128 == 0; auto for problems that leave CUs idle); 9 = persistent 128x128.
      * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default 8; 1 = plain N-fastest order). */
     int tile, group_m;
-    /* optional scratch made by vithip_gemm_f32_workspace_create() (uncached device memory, flags zeroed) and then left to the
-     * library (one per stream: launches that share it must be ordered).  With it, large problems whose tile count is not a multiple of the
+    /* optional scratch: the HANDLE made by vithip_gemm_f32_workspace_create() on the device the launch runs on (one per
+     * stream: launches that share it must be ordered).  With it, large problems whose tile count is not a multiple of the
      * workgroup count hand the first K-steps of the last round's tiles to the workgroups that would idle (bit-identical
-     * results: the accumulation chain moves between workgroups, it is not split; csrc/vit_gemm_persistent.hip).  NULL = off. */
+     * results: the accumulation chain moves between workgroups, it is not split; csrc/vit_gemm_persistent.hip).  Nobody
+     * waits in that hand-over: an owner that does not find its piece computes the whole tile.  NULL = off. */
     void *workspace;
+    /* testing: 1 = the helper workgroups run their pieces LAST, so that owners look for them too early and take the
+     * compute-it-yourself path (results must not change); 0 = normal. */
+    int handover_test;
 } vithip_gemm_args;
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
-size_t vithip_gemm_f32_workspace_bytes(void);
+size_t vithip_gemm_f32_workspace_bytes(void);             /* device bytes a workspace takes on the current device */
 int vithip_gemm_f32_workspace_create(void **workspace);   /* on the current device */
 int vithip_gemm_f32_workspace_destroy(void *workspace);
-/* after the stream's work is complete: *timed_out = 1 when an owner workgroup gave up (after ~60 ms) waiting for the piece a
- * helper was to deliver -- its tile is then wrong; clears the mark.  A bounded wait instead of a hang. */
-int vithip_gemm_f32_workspace_check(void *workspace, int *timed_out);
+/* Hand-over counters since the last call (blocking; the stream's launches should be complete): tiles finished from a parked
+ * piece / tiles an owner computed whole because the piece was not there yet.  Either pointer may be NULL.  Clears them. */
+int vithip_gemm_f32_workspace_stats(void *workspace, int *taken, int *recomputed);
+void *vithip_gemm_f32_workspace_device_ptr(void *workspace);  /* [flag per owner ... ][64 KB slots]; tests */
 /* ---- bf16 variant (BASELINE.json configs[2]) ---------------------------------
  * bf16 values are raw uint16 (upper half of the fp32 bit pattern, round-to-nearest-even). */
 enum { VITHIP_BF16_EPI_BF16 = 0, VITHIP_BF16_EPI_BF16_GELU = 1, VITHIP_BF16_EPI_F32_RESIDUAL = 2,

@@ -183,6 +183,67 @@ def test_concurrent_lanes_give_identical_results(b16, lanes):
     assert np.array_equal(got, ref)
 
 
+def _forward_device(eng, imgs):
+    """One vit_engine_forward_device call on HBM-resident images: the whole batch is ONE chunk (the host-pointer path cuts a
+    single chunk in two pieces to overlap its copies), i.e. the GEMM shapes bench.py times."""
+    n = imgs.shape[0]
+    d_in, d_out = B.DeviceArray.from_numpy(imgs), B.DeviceArray((n, 1000))
+    eng.forward_device(d_in.ptr, n, d_out.ptr)
+    eng.sync()
+    return d_out.numpy()
+
+
+def _batch256():
+    g = np.load(GOLD)
+    base = synth.make_images(synth.VIT_B16, 16, int(g["image_seed"]))  # images 0,1 are the golden ones
+    idx = (np.arange(256) % 16)[np.random.default_rng(1).permutation(256)]
+    return g, base[idx], idx
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_b16_batch256_lanes_with_handover_are_bit_identical(b16, lanes):
+    """The metric batch with 2 and 3 concurrent lanes: every lane's fc1 / fc2 / out_proj hands helper pieces over
+    (csrc/vit_gemm_persistent.hip) while the other lanes' kernels share the CUs, so a lane's 512 workgroups are NOT all
+    resident -- the case in which round 2's owner could wait for a helper that had not started.  Nothing waits now: an owner that
+    finds no piece computes its tile whole.  Results must equal the one-lane run bit for bit and the golden rows."""
+    eng, _ = b16
+    g, imgs, idx = _batch256()
+    eng.handover_stats()
+    ref = _forward_device(eng, imgs)
+    one = eng.handover_stats()
+    assert one["taken"] + one["recomputed"] == 12 * (316 + 316 + 240)   # owners per layer: out_proj, fc2 (2364 tiles - 4 x 512), fc1 (9456 - 18 x 512)
+    eng.set_lanes(lanes)
+    try:
+        got = _forward_device(eng, imgs)
+        many = eng.handover_stats()
+    finally:
+        eng.set_lanes(1)
+    assert np.array_equal(got, ref)
+    assert many["taken"] + many["recomputed"] > 0
+    print(f"hand-overs: 1 lane {one}, {lanes} lanes {many}")
+    for k in (0, 1):
+        row = got[idx == k][0]
+        assert float(np.abs(row - g["probs"][k]).max()) <= PROB_TOL
+        assert int(row.argmax()) == int(g["probs"][k].argmax())
+
+
+def test_b16_batch256_with_late_helpers_is_bit_identical(b16):
+    """`gemm_handover_test = 1`: every helper workgroup runs its pieces LAST, so the owners look for them too early, withdraw
+    and compute their tiles whole (and the helpers, arriving late, clear the withdrawn marks).  Same bits as the normal run."""
+    eng, W = b16
+    g, imgs, idx = _batch256()
+    ref = _forward_device(eng, imgs)
+    late = B.Engine(synth.VIT_B16, max_batch=256, gemm_handover_test=1)
+    try:
+        late.copy_weights_from(eng)
+        got = _forward_device(late, imgs)
+        st = late.handover_stats()
+    finally:
+        late.close()
+    assert np.array_equal(got, ref)
+    assert st["recomputed"] > 0 and st["taken"] + st["recomputed"] == 12 * (316 + 316 + 240), st
+
+
 def test_empty_and_invalid_inputs(b16):
     """Empty input: the facade is a no-op for image[0].n == 0 (the reference's loop simply would not run,
     ViT_opencl.c:802); the engine API rejects n <= 0 and NULL rows with an error code instead of crashing."""

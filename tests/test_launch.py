@@ -4,6 +4,7 @@ import importlib
 import io
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -61,4 +62,5 @@ def test_bench_parent_spawns_before_touching_torch_or_hip():
     last = [l for l in r.stdout.splitlines() if l.startswith("PARENT")][-1]
     assert last.endswith("[]"), r.stdout + r.stderr              # neither torch nor the binding in the parent
     assert " 0 " not in last                                      # ranks failed (no GPU) and the parent said so
-    assert "[rank 1]" in r.stderr and "needs a GPU" in r.stderr
+    # whichever rank fails first stops the other (launch_ranks terminates the rest), so only ONE message is guaranteed
+    assert re.search(r"\[rank [01]\] .*needs a GPU", r.stderr), r.stderr

@@ -48,7 +48,8 @@ class CImageData(C.Structure):  # Network.h:7-13
 
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
-                ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int), ("ln_fold", C.c_int)]
+                ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int), ("ln_fold", C.c_int),
+                ("gemm_handover_test", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -65,7 +66,8 @@ class CGemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("epilogue", C.c_int), ("tile", C.c_int), ("group_m", C.c_int), ("workspace", C.c_void_p)]
+                ("epilogue", C.c_int), ("tile", C.c_int), ("group_m", C.c_int), ("workspace", C.c_void_p),
+                ("handover_test", C.c_int)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -204,9 +206,11 @@ class DeviceArray:
             pass
 
 
-def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: int = 0, workspace: bool = False) -> np.ndarray:
+def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: int = 0, workspace: bool = False,
+         handover_test: int = 0, stats: Optional[dict] = None) -> np.ndarray:
     """C = epilogue(A . W^T + bias) through vithip_gemm_f32 (tile / group_m: per-call tuning fields, 0 = auto;
-    workspace: lend the scratch that enables the helper pieces of the persistent walk)."""
+    workspace: lend the scratch that enables the helper pieces of the persistent walk; handover_test: see
+    vithip_gemm_args; stats: receives the hand-over counters {"taken", "recomputed"} of the launch)."""
     A, W, bias = _as_f32(A), _as_f32(W), _as_f32(bias)
     M, K = A.shape
     N = W.shape[0]
@@ -214,19 +218,44 @@ def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: i
     dC = DeviceArray((M, N))
     dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
     ws = gemm_workspace() if workspace else None
-    args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue, tile, group_m, ws)
+    args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue, tile, group_m, ws,
+                     handover_test)
     hip_check(lib().vithip_gemm_f32(None, C.byref(args)), "vithip_gemm_f32")
     out = dC.numpy()
     if ws:
+        if stats is not None:
+            stats.update(gemm_workspace_stats(ws))
         lib().vithip_gemm_f32_workspace_destroy(C.c_void_p(ws))
     return out
 
 
 def gemm_workspace() -> int:
-    """vithip_gemm_f32_workspace_create: the scratch of vithip_gemm_args.workspace (free with vithip_gemm_f32_workspace_destroy)."""
+    """vithip_gemm_f32_workspace_create: the handle for vithip_gemm_args.workspace (free with vithip_gemm_f32_workspace_destroy)."""
     p = C.c_void_p()
     hip_check(lib().vithip_gemm_f32_workspace_create(C.byref(p)), "vithip_gemm_f32_workspace_create")
     return p.value
+
+
+def gemm_workspace_stats(ws: int) -> dict:
+    """vithip_gemm_f32_workspace_stats: hand-overs since the last call (syncs the device first)."""
+    L = lib()
+    hip_check(L.vithip_device_sync(), "vithip_device_sync")
+    t, r = C.c_int(), C.c_int()
+    L.vithip_gemm_f32_workspace_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    hip_check(L.vithip_gemm_f32_workspace_stats(ws, C.byref(t), C.byref(r)), "vithip_gemm_f32_workspace_stats")
+    return {"taken": t.value, "recomputed": r.value}
+
+
+def gemm_workspace_flags(ws: int, count: int = 1016) -> np.ndarray:
+    """The per-owner flags of a workspace (0 = empty after every complete launch)."""
+    L = lib()
+    L.vithip_gemm_f32_workspace_device_ptr.restype = C.c_void_p
+    L.vithip_gemm_f32_workspace_device_ptr.argtypes = [C.c_void_p]
+    flags = np.empty(count, np.int32)
+    hip_check(L.vithip_device_sync(), "sync")
+    hip_check(L.vithip_memcpy_d2h(flags.ctypes.data, L.vithip_gemm_f32_workspace_device_ptr(ws), flags.nbytes, None), "d2h")
+    hip_check(L.vithip_device_sync(), "sync")
+    return flags
 
 
 class CGemmBf16Args(C.Structure):
@@ -448,12 +477,12 @@ class Engine:
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
                  lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False,
-                 gemm_tile: int = 0, ln_fold: int = 0):
+                 gemm_tile: int = 0, ln_fold: int = 0, gemm_handover_test: int = 0):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
         opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
-                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold)
+                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold, gemm_handover_test)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"
@@ -508,6 +537,14 @@ class Engine:
         out = np.empty((rows, self.cfg.num_classes), np.float32)
         self._check(lib().vit_engine_read_logits(self._h, out.ctypes.data_as(f32p), rows), "vit_engine_read_logits")
         return out
+
+    def handover_stats(self) -> dict:
+        """vit_engine_handover_stats: fp32 GEMM helper pieces taken / recomputed since the last call (syncs the device)."""
+        L = lib()
+        t, r = C.c_long(), C.c_long()
+        L.vit_engine_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        self._check(L.vit_engine_handover_stats(self._h, C.byref(t), C.byref(r)), "vit_engine_handover_stats")
+        return {"taken": int(t.value), "recomputed": int(r.value)}
 
     def set_lanes(self, lanes: int) -> None:
         L = lib()

@@ -27,6 +27,8 @@
 //    XCD's L2 once and reused by all its N tiles.
 //  * The implicit-GEMM variant (patch embedding) gathers A straight from NCHW images and
 //    fuses "+ pos_emb" and the token-row remap into the store.
+#include <new>
+
 #include "vit_gemm_common.hpp"
 #ifdef VIT_PROBES
 #include "vit_probes.h"
@@ -35,7 +37,7 @@
 namespace vitgemm {
 int launch_persistent(hipStream_t stream, GemmParams &p, int epilogue, int group_m);  // vit_gemm_persistent.hip
 int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, int group_m);
-int persistent_piece_steps(int M, int N, int K);
+int persistent_piece_steps(int M, int N, int K, int slots, int wgs);
 }
 
 namespace {
@@ -414,7 +416,7 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
                 // with a workspace the persistent walk hands the first K-steps of the partial last round's tiles to idle
                 // workgroups (fc2 / out_proj at batch 256: 480 -> 448 steps per workgroup); without one the residual
                 // epilogue is marginally faster one tile per workgroup (fc2 21.30 vs 21.43 ms per step)
-                if (p.sk_ws && vitgemm::persistent_piece_steps(p.M, p.N, p.K) > 0) return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
+                if (p.sk_ws && vitgemm::persistent_piece_steps(p.M, p.N, p.K, p.sk_slots, 0) > 0) return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
                 return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
             }
             if (tiles < 2048) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
@@ -450,31 +452,67 @@ int vithip_gemm_set_group(int group_m) {
 }
 #endif
 
-size_t vithip_gemm_f32_workspace_bytes(void) { return 4096 + (size_t)1024 * 128 * 128 * 4; }  // flags + one slot per workgroup (<= 2 x 512 CUs)
+// ---- the scratch of vithip_gemm_args.workspace ----------------------------------------------------------------------------
+// A host-side handle around UNCACHED device memory (accesses bypass the per-XCD L2s, so the workgroup that parks accumulators
+// and the one that picks them up need no cache maintenance): [4 KB: one flag per owner workgroup, two counters]
+// [one 64 KB slot per owner].  Owners are the first R < grid <= 2 x CUs workgroups, so 2 x CUs slots cover every launch on the
+// device the workspace was made on.
+struct GemmWorkspace {
+    void *dev;
+    int slots;
+    int device;
+};
+static size_t workspace_dev_bytes(int slots) { return 4096 + (size_t)slots * 128 * 128 * 4; }
 
-// The scratch of vithip_gemm_args.workspace: uncached device memory (accesses bypass the per-XCD L2s, so the workgroup that
-// parks accumulators and the one that picks them up need no cache maintenance), flags zeroed.
+size_t vithip_gemm_f32_workspace_bytes(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return workspace_dev_bytes(2 * cus);
+}
+
 int vithip_gemm_f32_workspace_create(void **ws) {
     if (!ws) return static_cast<int>(hipErrorInvalidValue);
     *ws = nullptr;
-    hipError_t e = hipExtMallocWithFlags(ws, vithip_gemm_f32_workspace_bytes(), hipDeviceMallocUncached);
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return static_cast<int>(e);
-    e = hipMemset(*ws, 0, 4096);
+    GemmWorkspace *w = new (std::nothrow) GemmWorkspace{nullptr, 2 * cus, dev};
+    if (!w) return static_cast<int>(hipErrorOutOfMemory);
+    e = hipExtMallocWithFlags(&w->dev, workspace_dev_bytes(w->slots), hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(w->dev, 0, 4096);
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { (void)hipFree(*ws); *ws = nullptr; }
+    if (e != hipSuccess) {
+        if (w->dev) (void)hipFree(w->dev);
+        delete w;
+        return static_cast<int>(e);
+    }
+    *ws = w;
+    return 0;
+}
+int vithip_gemm_f32_workspace_destroy(void *ws) {
+    if (!ws) return 0;
+    GemmWorkspace *w = static_cast<GemmWorkspace *>(ws);
+    const hipError_t e = hipFree(w->dev);
+    delete w;
     return static_cast<int>(e);
 }
-int vithip_gemm_f32_workspace_destroy(void *ws) { return ws ? static_cast<int>(hipFree(ws)) : 0; }
-// *timed_out = 1 if, since the last check, an owner workgroup gave up waiting for its helper's piece (its tile is then wrong).
-// Blocking (the stream's work must be complete for the answer to mean anything); clears the mark.
-int vithip_gemm_f32_workspace_check(void *ws, int *timed_out) {
-    if (!ws || !timed_out) return static_cast<int>(hipErrorInvalidValue);
-    int mark = 0;
-    hipError_t e = hipMemcpy(&mark, static_cast<char *>(ws) + 4092, sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && mark) e = hipMemset(static_cast<char *>(ws) + 4092, 0, sizeof(int));
-    *timed_out = mark != 0;
+// Hand-overs since the last call: *taken = tiles an owner finished from a parked piece, *recomputed = tiles an owner ran whole
+// because the piece was not there when it looked (never a wrong result, x K-steps of one workgroup lost).  Blocking (the
+// stream's launches must be complete for the numbers to be final); clears the counters.
+int vithip_gemm_f32_workspace_stats(void *ws, int *taken, int *recomputed) {
+    if (!ws) return static_cast<int>(hipErrorInvalidValue);
+    GemmWorkspace *w = static_cast<GemmWorkspace *>(ws);
+    int c[2] = {0, 0};
+    char *at = static_cast<char *>(w->dev) + 1016 * sizeof(int);
+    hipError_t e = hipMemcpy(c, at, sizeof(c), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && (c[0] || c[1])) e = hipMemset(at, 0, sizeof(c));
+    if (taken) *taken = c[0];
+    if (recomputed) *recomputed = c[1];
     return static_cast<int>(e);
 }
+// The device side of the handle (tests read the flags through it).
+void *vithip_gemm_f32_workspace_device_ptr(void *ws) { return ws ? static_cast<GemmWorkspace *>(ws)->dev : nullptr; }
 
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);
@@ -493,8 +531,15 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.R = a->residual; p.C = a->C;
     p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
     p.M = a->M; p.N = a->N; p.K = a->K;
-    p.sk_ws = a->workspace;
-    if (a->workspace && (reinterpret_cast<size_t>(a->workspace) & 15)) return static_cast<int>(hipErrorInvalidValue);
+    if (a->workspace) {
+        const GemmWorkspace *w = static_cast<const GemmWorkspace *>(a->workspace);
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != w->device) return static_cast<int>(hipErrorInvalidDevice);  // made on another device
+        p.sk_ws = w->dev;
+        p.sk_slots = w->slots;
+        p.sk_late = a->handover_test == 1;
+    }
+    if (a->handover_test < 0 || a->handover_test > 1) return static_cast<int>(hipErrorInvalidValue);
     if (a->tile < 0 || a->tile > 12 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
     return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue, a->tile, a->group_m);
 }

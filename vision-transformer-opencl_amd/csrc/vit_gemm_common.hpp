@@ -11,6 +11,7 @@ namespace vitgemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KALIGN = 32;  // K must be a multiple of this (covers both K steps below)
 
@@ -35,8 +36,10 @@ struct GemmParams {
     int img;         // S
     int chans;       // C
     // persistent kernel, helper pieces (vit_gemm_persistent.hip): workspace lent by the caller (NULL: off), piece length
-    void *sk_ws;
+    void *sk_ws;     // device side of the workspace handle: [4 KB of flags and counters][sk_slots x 64 KB]
+    int sk_slots;
     int sk_x;
+    int sk_late;     // tests: helpers run their pieces last (vithip_gemm_args.handover_test)
 };
 
 // erf(x) = sign(x) * (1 - exp(t*q(t))), t = min(|x|, 4), q = degree-7 minimax fit of log(erfc(t))/t

@@ -25,14 +25,22 @@
 // bit-identical to the one-workgroup tile (tests/test_gpu_ops.py::test_gemm_tile_shapes_are_bit_identical), which plain
 // split-K / stream-K fix-ups are not.  With c = ceil(owners / helpers) pieces per helper and x = floor(nk / (c + 1)) every workgroup
 // ends within full x nk + c x steps: fc2 448 instead of 480 (ideal 443.25), out_proj 112 / 120, fc1 444 / 456.
-// Dependencies: a helper waits for nobody; an owner waits, after all its own tiles, for a piece its helper finished first thing.
-// The wait is bounded (it gives up after ~60 ms and the result is wrong, not hung).
+// Dependencies: NOBODY WAITS (round 3).  A helper runs its pieces first thing and waits for nobody.  An owner looks at its
+// slot's flag ONCE, three K-steps before its load cursor enters the extra tile (about 380 steps after the helper finished in the
+// resident case): piece there -> its walk ends with [x, nk) from the parked accumulators; piece not there (helper not resident
+// yet: another lane's or process's kernels hold its CU, ...) -> the owner withdraws the request (flag 0 -> 2) and runs the
+// whole tile [0, nk) itself, the helper finds the 2 when it parks and clears it.  Either way every output sums its k in the
+// same order: no code path stores a tile whose accumulators it did not wait for, nothing spins, nothing can time out, and
+// the hand-over needs no co-residency of the grid (lanes > 1, shared devices).  The two outcomes are counted in the
+// workspace (vithip_gemm_f32_workspace_stats): a recomputed piece costs x K-steps of one workgroup, never a wrong bit.
 #include "vit_gemm_common.hpp"
 
 namespace vitgemm {
 
 constexpr int PBK = 32;           // K step
 constexpr int PLD = PBK + 4;      // padded LDS row (floats)
+// workspace: [SK_HEADER_BYTES of ints: flag per owner | two counters] [slots of 128 x 128 x 4 bytes]
+constexpr int SK_HEADER_BYTES = 4096, SK_MAX_OWNERS = 1000, SK_STAT_TAKEN = 1016, SK_STAT_RECOMPUTED = 1017;
 
 // SK: helper pieces compiled in (launches without them use the SK = false instantiation: no segment bookkeeping in its registers)
 template <int BM, int BN, int WM, int WN, int EPI, bool STAMP = false, bool SK = false>
@@ -48,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     static_assert((BM / WM) * WGN == 4, "4 waves per workgroup");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PLD];
+    __shared__ int sk_decision;  // owner: 1 = the helper's piece is there (written by thread 0, read by all after a barrier)
     float *const As0 = lds;
     float *const Bs0 = lds + 2 * BM * PLD;
 
@@ -76,17 +85,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     const int H = nwg - R;
     const bool owner = first < R;
     const int npre = (x > 0 && !owner && R > 0) ? (R - (first - R) + H - 1) / H : 0;  // owners first-R, first-R+H, ...
+    // p.sk_late (tests): a helper runs its pieces AFTER its own tiles, i.e. too late for the owners' look at the flag
+    const int pstart = (SK && p.sk_late) ? full : 0, fstart = (SK && p.sk_late) ? 0 : npre;
     const int nseg = npre + full + (owner ? 1 : 0);
+    bool took = false;                           // owner: the parked piece is the start of its extra tile (set by decide())
     struct Seg { int tile, k0, k1, in, out; };
     auto get_seg = [&](int i) -> Seg {
         Seg g;
-        if (i < npre) {
-            const int o = (first - R) + i * H;
+        if (i >= pstart && i < pstart + npre) {
+            const int o = (first - R) + (i - pstart) * H;
             g.tile = full * nwg + o; g.k0 = 0; g.k1 = x; g.in = -1; g.out = o;
         } else if (i < npre + full) {
-            g.tile = first + (i - npre) * nwg; g.k0 = 0; g.k1 = nk; g.in = -1; g.out = -1;
+            g.tile = first + (i - fstart) * nwg; g.k0 = 0; g.k1 = nk; g.in = -1; g.out = -1;
         } else {
-            g.tile = first + full * nwg; g.k0 = x; g.k1 = nk; g.in = x > 0 ? first : -1; g.out = -1;
+            g.tile = first + full * nwg; g.k0 = took ? x : 0; g.k1 = nk; g.in = took ? first : -1; g.out = -1;
         }
         return g;
     };
@@ -127,6 +139,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         }
     };
 
+    // ---- the owner's one look at its slot (workgroup-uniform: thread 0 decides, a barrier and an LDS word tell the rest) -----
+    // flag o: 0 empty, 1 piece parked, 2 request withdrawn.  Relaxed agent-scope atomics on an uncached word; what orders the
+    // DATA against the flag is on the helper's side (park()).  Whatever value a broken earlier run may have left, only an
+    // observed 1 makes the owner read the slot, and a 1 is only ever written behind this launch's data.
+    int *const sk_flags = reinterpret_cast<int *>(p.sk_ws);
+    int steps = 0;                               // K-steps of the whole walk (loop trip count; decide() may shorten it)
+    auto decide = [&]() {
+        if (tid == 0) {
+            int *const f = sk_flags + first;
+            int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 1) {
+                int expected = 0;
+                v = __hip_atomic_compare_exchange_strong(f, &expected, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 2 : expected;
+            }
+            // taken: the slot is free again as soon as this KERNEL ends (its next writer is a later launch on this stream)
+            if (v == 1) __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sk_flags + (v == 1 ? SK_STAT_TAKEN : SK_STAT_RECOMPUTED), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_decision = v == 1;
+        }
+        __syncthreads();
+        took = __builtin_amdgcn_readfirstlane(sk_decision) != 0;
+        if (took) steps -= x;
+    };
+
     // ---- load cursor: the (segment, k-step) the NEXT staging load will fetch ----------------------
     int seg_l = 0, k_l, kend_l;
     {
@@ -139,6 +175,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         if (++k_l == kend_l) {
             // past the last segment the old sources stay: harmless re-reads into a buffer nobody uses
             if (++seg_l < nseg) {
+                // the load cursor runs three K-steps ahead of the MFMAs: entering the owner's extra tile is where its first
+                // K-step -- x or 0 -- has to be known
+                if (SK && owner && x > 0 && seg_l == nseg - 1) decide();
                 const Seg g = get_seg(seg_l);
                 set_sources(g.tile);
                 k_l = g.k0;
@@ -190,12 +229,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * PLD);
     };
 
-    // ---- parked accumulators: slot o = 64 KB, float4 q of thread t at ((q * 256 + t) * 16) bytes; flag o: 0 empty, 1 ready ----
+    // ---- parked accumulators: slot o = 64 KB, float4 q of thread t at ((q * 256 + t) * 16) bytes --------------------------
+    // Every access to a slot is a SYSTEM-scope (sc0 sc1) buffer access to UNCACHED device memory: the store is written
+    // through to memory and acknowledged (vmcnt) once it is there, the load is served from memory, whichever XCD either side
+    // runs on.  A release fence at agent scope would add buffer_wbl2 -- a write-back of the XCD's whole L2, there for ORDINARY
+    // stores, of which the hand-over has none (measured with such fences: out_proj +22 %, the A / W panels of the XCD's 63
+    // other workgroups went out with it).  What a release needs of these stores is that they have COMPLETED before the flag
+    // goes up: every thread waits for its own (s_waitcnt vmcnt(0), written out: a workgroup-scope fence only emits
+    // lgkmcnt(0) on gfx950), then the workgroup barrier, then thread 0's flag.
     f32x16 acc[TM][TN];
-    int *const sk_flags = reinterpret_cast<int *>(p.sk_ws);
-    auto slot_ptr = [&](int o) { return reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.sk_ws) + 4096 + (size_t)o * (BM * BN * 4)); };
-    auto park = [&](int o) {  // helper: accumulators -> slot o, then the flag (release: the owner may sit on another XCD)
-        f32x4 *dst = slot_ptr(o) + tid;
+    constexpr int SC_SYS = 0x11;  // cache policy of the raw buffer builtins on gfx94x/95x: bit 0 = sc0, bit 4 = sc1
+    auto slot_rsrc = [&](int o) {
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.sk_ws) + SK_HEADER_BYTES + (size_t)o * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
+    };
+    auto park = [&](int o) {  // helper: accumulators -> slot o, then the flag
+        const __amdgpu_buffer_rsrc_t rs = slot_rsrc(o);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -205,40 +253,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
-                    dst[((i * TN + j) * 4 + q4) * 256] = v;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, tid * 16,
+                                                           ((i * TN + j) * 4 + q4) * 4096, SC_SYS);
                 }
-        // The workspace is UNCACHED device memory (vithip_gemm_f32_workspace_create): stores go to memory, loads come from
-        // it, whichever XCD either side runs on.  So no agent-scope fences here: a release / acquire at agent scope writes
-        // back / invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1), which threw the A and W panels of the 63
-        // other workgroups of the XCD out with it (out_proj +22 % with them).  All that is needed is that every thread's
-        // stores have completed before the flag goes up: vmcnt(0), then the workgroup barrier.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(sk_flags + o, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto unpark = [&](int o) {  // owner: wait for the piece (bounded), take it as the initial accumulators, free the slot
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(sk_flags + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 18))
-                __builtin_amdgcn_s_sleep(8);
-            // gave up: the result of this tile is wrong.  Leave a mark the host can see (vithip_gemm_f32_workspace_check)
-            if (spins >= (1 << 18)) __hip_atomic_store(sk_flags + 1023, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int expected = 0;  // 0 -> 1: parked.  Found 2: the owner has withdrawn and computes the tile itself -> clear the mark
+            if (!__hip_atomic_compare_exchange_strong(sk_flags + o, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                __hip_atomic_store(sk_flags + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();  // (uncached memory: nothing stale to drop, see park())
-        const f32x4 *src = slot_ptr(o) + tid;
+    };
+    auto unpark = [&](int o) {  // owner, after decide() saw the flag: the piece is its initial accumulators
+        const __amdgpu_buffer_rsrc_t rs = slot_rsrc(o);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x4 v = src[((i * TN + j) * 4 + q4) * 256];
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, ((i * TN + j) * 4 + q4) * 4096, SC_SYS));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * q4 + e] = v[e];
                 }
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(sk_flags + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
     };
 
     // ---- compute cursor --------------------------------------------------------------------------
@@ -267,6 +304,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     };
     begin_segment(0);
 
+    for (int i = 0; i < nseg; ++i) {  // (an owner's extra tile counts in full until decide() says otherwise)
+        const Seg g = get_seg(i);
+        steps += g.k1 - g.k0;
+    }
     // ---- prologue (once per workgroup, not per tile): steps 0 and 1 -----------------------------
     load_step();
     advance_load_cursor();
@@ -278,11 +319,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
 
     if constexpr (STAMP) st_loop0 = __builtin_amdgcn_s_memtime();
     int cur = 0;
-    int steps = 0;
-    for (int i = 0; i < nseg; ++i) {
-        const Seg g = get_seg(i);
-        steps += g.k1 - g.k0;
-    }
     for (int g = 0; g < steps; ++g) {
         const int k_ahead = k_l * PBK;  // offset of the step the restage loads fetch (step g + 2)
 #pragma unroll
@@ -332,19 +368,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     }
 }
 
-int g_persistent_wgs = 0;  // 2 per CU, queried once
+// 2 workgroups per CU of the CURRENT device (engines of several devices share the process: nothing is cached process-wide)
+static int persistent_wgs() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return 2 * cus;
+}
 
 // K-steps of a last-round tile that a helper workgroup runs (0: the hand-over does not pay) for the 128 x 128 persistent walk
-int persistent_piece_steps(int M, int N, int K) {
-    if (g_persistent_wgs == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        g_persistent_wgs = 2 * cus;
-    }
+// on a grid of `wgs` workgroups (0: ask the current device) with `slots` parking slots
+int persistent_piece_steps(int M, int N, int K, int slots, int wgs) {
+    if (wgs <= 0) wgs = persistent_wgs();
+    if (wgs <= 0) return 0;
     const int total = ((M + 127) / 128) * ((N + 127) / 128);
-    const int nwg = total < g_persistent_wgs ? total : g_persistent_wgs;
+    const int nwg = total < wgs ? total : wgs;
     const int full = total / nwg, R = total - full * nwg, nk = K / PBK;
-    if (full < 1 || R <= 0 || R >= nwg) return 0;
+    if (full < 1 || R <= 0 || R >= nwg || R > slots || R > SK_MAX_OWNERS) return 0;
     const int c = (R + (nwg - R) - 1) / (nwg - R);
     const int x = nk / (c + 1);
     // a hand-over costs about 3 K-steps (64 KB out, 64 KB in through uncached memory, the flag): worth it when the walk gets
@@ -355,21 +394,16 @@ int persistent_piece_steps(int M, int N, int K) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_persistent_tile(hipStream_t stream, GemmParams &p, int epilogue, int group_m) {
-    if (g_persistent_wgs == 0) {
-        int dev = 0, cus = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return static_cast<int>(e);
-        g_persistent_wgs = 2 * cus;
-    }
+    const int wgs = persistent_wgs();
+    if (wgs <= 0) return static_cast<int>(hipErrorInvalidDevice);
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.group_m = group_m;
     const int total = p.tiles_m * p.tiles_n;
-    const dim3 grid(total < g_persistent_wgs ? total : g_persistent_wgs), block(256);
+    const dim3 grid(total < wgs ? total : wgs), block(256);
     // helper pieces (see the head of this file): on when the caller lent a workspace, a partial last round exists and the
     // piece is long enough to be worth a 64 KB hand-over (>= 4 K-steps)
-    p.sk_x = (p.sk_ws && BM == 128 && BN == 128) ? persistent_piece_steps(p.M, p.N, p.K) : 0;
+    p.sk_x = (p.sk_ws && BM == 128 && BN == 128) ? persistent_piece_steps(p.M, p.N, p.K, p.sk_slots, wgs) : 0;
     if (p.sk_x > 0) {
         switch (epilogue) {
             case VITHIP_EPI_BIAS:
@@ -405,17 +439,13 @@ int launch_persistent_tile(hipStream_t stream, GemmParams &p, int epilogue, int 
 #ifdef VIT_PROBES
 // Stamped probe build (tools/gemm_probe.py --stamp-tile 129): p.dbg receives 8 x u64 per workgroup.
 int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, int group_m) {
-    if (g_persistent_wgs == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return static_cast<int>(hipErrorInvalidDevice);
-        g_persistent_wgs = 2 * cus;
-    }
+    const int wgs = persistent_wgs();
+    if (wgs <= 0) return static_cast<int>(hipErrorInvalidDevice);
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = (p.N + 127) / 128;
     p.group_m = group_m;
     const int total = p.tiles_m * p.tiles_n;
-    const dim3 grid(total < g_persistent_wgs ? total : g_persistent_wgs), block(256);
+    const dim3 grid(total < wgs ? total : wgs), block(256);
     if (epilogue == VITHIP_EPI_BIAS_GELU)
         hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, VITHIP_EPI_BIAS_GELU, true>), grid, block, 0, stream, p);
     else

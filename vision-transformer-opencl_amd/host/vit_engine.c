@@ -45,7 +45,8 @@ struct vit_engine {
     unsigned short *wfold16;     /* per layer [gamma1-folded in_proj 3D x D | gamma2-folded fc1 H x D] (bf16) */
     float *wfoldf;               /* per layer [colsum qkv 3D | bias qkv 3D | colsum fc1 H | bias fc1 H] */
     int lane_cap;                /* most images one lane may hold (32-bit buffer offsets of the fp32 kernels) */
-    void *gemm_ws[VIT_MAX_LANES]; /* per lane (= per stream): vithip_gemm_args.workspace, zeroed once */
+    void *gemm_ws[VIT_MAX_LANES]; /* per lane in use (= per stream): vithip_gemm_args.workspace handles */
+    long handover_taken, handover_recomputed;
     /* use_graph: the captured forward and what it was captured for */
     vithip_graph_t graph;
     const float *g_images; float *g_probs; int *g_label; float *g_prob; int g_n;
@@ -129,6 +130,7 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->use_graph = 0;
     opt->gemm_tile = 0;
     opt->ln_fold = 0;
+    opt->gemm_handover_test = 0;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -165,6 +167,14 @@ static int check_config(vit_engine *e) {
     if (c->patch_size % 4 || c->img_size % 4 || (c->in_chans * c->patch_size * c->patch_size) % 32)
         return fail(e, VIT_ERR_ARG, "patch geometry unsupported (patch%%4, img%%4, C*P*P%%32 must be 0)");
     if (c->embed_dim > 2048) return fail(e, VIT_ERR_ARG, "embed_dim > 2048 unsupported by the LayerNorm kernel");
+    return VIT_OK;
+}
+
+/* One hand-over workspace per lane in use (fp32 engines; 32 MB of uncached device memory each on a 256-CU device). */
+static int ensure_gemm_workspaces(vit_engine *e) {
+    if (e->opt.dtype != VIT_DTYPE_F32) return VIT_OK;
+    for (int j = 0; j < e->opt.lanes && j < VIT_MAX_LANES; ++j)
+        if (!e->gemm_ws[j]) HIP_TRY(e, vithip_gemm_f32_workspace_create(&e->gemm_ws[j]));
     return VIT_OK;
 }
 
@@ -218,8 +228,11 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
     HIP_TRY(e, vithip_malloc((void **)&e->hbuf, B * T * H * sizeof(float)));
     HIP_TRY(e, vithip_malloc((void **)&e->z, B * D * sizeof(float)));
     HIP_TRY(e, vithip_malloc((void **)&e->logits, B * NC * sizeof(float)));
-    if (e->opt.dtype == VIT_DTYPE_F32)
-        for (int j = 0; j < VIT_MAX_LANES; ++j) HIP_TRY(e, vithip_gemm_f32_workspace_create(&e->gemm_ws[j]));
+    if (e->opt.lanes > VIT_MAX_LANES) e->opt.lanes = VIT_MAX_LANES;
+    {
+        int rc_ws = ensure_gemm_workspaces(e);
+        if (rc_ws) return rc_ws;
+    }
     if (e->opt.dtype == VIT_DTYPE_BF16 && e->opt.ln_fold >= 0) {
         /* the fold lives in the ping-pong GEMM (two K steps at least); its scratch (bf16 copy of x, row sums) uses the
          * idle halves of the y and qkv allocations, which bf16 activations only half fill */
@@ -290,7 +303,8 @@ int vit_engine_set_lanes(vit_engine *e, int lanes) {
     if (!e) return VIT_ERR_ARG;
     if (lanes < 1 || lanes > VIT_MAX_LANES) return fail(e, VIT_ERR_ARG, "lanes must be 1..%d", VIT_MAX_LANES);
     e->opt.lanes = lanes;
-    return VIT_OK;
+    HIP_TRY(e, vithip_set_device(e->opt.device));
+    return ensure_gemm_workspaces(e);
 }
 
 int vit_engine_set_profile(vit_engine *e, int on) {
@@ -450,10 +464,13 @@ static int stage_end(vit_engine *e, vithip_stream_t s) {
 static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int lda, const float *W,
                 const float *bias, const float *res, float *C, int ldc, int M, int N, int K, int epi) {
     vithip_gemm_args a;
-    a.workspace = NULL; /* the lane's workspace: launches on one stream are ordered, which is what sharing it needs */
-    if (s == e->stream || e->opt.lanes == 1) a.workspace = e->gemm_ws[0];
+    memset(&a, 0, sizeof(a));
+    /* the lane's workspace: launches on one stream are ordered, which is what sharing it needs.  Lane 0 runs on the caller's
+     * stream (whatever it is), lane j on aux_stream[j - 1]. */
+    a.workspace = e->gemm_ws[0];
     for (int j = 0; j < VIT_MAX_LANES - 1; ++j)
         if (s == e->aux_stream[j]) a.workspace = e->gemm_ws[j + 1];
+    a.handover_test = e->opt.gemm_handover_test;
     a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
     a.tile = e->opt.gemm_tile; a.group_m = 0;
@@ -943,15 +960,27 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
             memcpy(probs[first + i], e->pin_out[b] + (size_t)i * NC, NC * sizeof(float));
     }
 #undef PIECE_N
-    for (int j = 0; j < VIT_MAX_LANES; ++j) { /* everything above is complete: did a GEMM hand-over give up waiting? */
-        int timed_out = 0;
-        if (e->gemm_ws[j]) HIP_TRY(e, vithip_gemm_f32_workspace_check(e->gemm_ws[j], &timed_out));
-        if (timed_out) return fail(e, VIT_ERR_HIP, "a GEMM workgroup gave up waiting for its helper piece (lane %d): results are invalid", j);
-    }
     if (e->opt.profile) {
         int rc = collect_profile(e);
         if (rc) return rc;
     }
+    return VIT_OK;
+}
+
+int vit_engine_handover_stats(vit_engine *e, long *taken, long *recomputed) {
+    if (!e) return VIT_ERR_ARG;
+    HIP_TRY(e, vithip_set_device(e->opt.device));
+    HIP_TRY(e, vithip_device_sync()); /* lanes and caller-provided streams */
+    for (int j = 0; j < VIT_MAX_LANES; ++j) {
+        int t = 0, r = 0;
+        if (!e->gemm_ws[j]) continue;
+        HIP_TRY(e, vithip_gemm_f32_workspace_stats(e->gemm_ws[j], &t, &r));
+        e->handover_taken += t;
+        e->handover_recomputed += r;
+    }
+    if (taken) *taken = e->handover_taken;
+    if (recomputed) *recomputed = e->handover_recomputed;
+    e->handover_taken = e->handover_recomputed = 0;
     return VIT_OK;
 }
 
