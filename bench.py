@@ -11,6 +11,14 @@ the end of each step (the only exchange the north star asks for).  One JSON line
 Extra objects in the line:
   roofline      the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs per launch / average launch
                 duration from HIP events recorded on the launch stream during the timed steps.
+  golden        every rank's batch starts with the two images of tests/golden/vit_b16_e2e.npz (probabilities written by the
+                reference's own ViT_seq(), oracle/gen_golden.py): rows 0-1 of the timed steps' output are checked against them
+                on every rank, at any N (1e-4 fp32 / 2e-2 bf16, identical top-1); with N > 1 rank 0 also checks every rank's
+                slot of the RCCL gather (against a broadcast of that rank's records and against the golden labels).
+                Any failure sets "ok": false and the exit code.
+  c_surface     N = 1: the same batch through vit_engine_forward_host -- what ViT_opencl(ImageData*, Network*, float**) does
+                underneath (separately allocated host images in, host probability rows out: H2D and D2H inside the time,
+                Main.c:55-60 times exactly that call).  Never `value`.
   cpu_baseline  the reference's own ViT_seq() (oracle/_ref, compiled from its ViT_seq.c) when that library is
                 present, else the CPU oracle (bit-identical restatement), timed on one host core on one
                 image of the same batch; the GPU row for that image is checked against it (1e-4 on
@@ -139,10 +147,17 @@ def main() -> None:
     ap.add_argument("--ln-fold", type=int, default=0, choices=(-1, 0, 1),
                     help="bf16: fold the encoder LayerNorms into the GEMMs either side (0 auto = on, -1 off: LayerNorm kernels)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 1, 2, 3, 4),
+                    help="BASELINE.json configs[i] preset: 1 = fp32 batch 256 (the metric, the default), 2 = bf16 batch 2048, "
+                         "3 = bf16 2048 per GPU (global 16384 at --gpus 8), 4 = ViT-L/16-384 bf16 batch 1024")
+    ap.add_argument("--no-c-surface", action="store_true", help="skip the host-pointer (ViT_opencl-shaped) timing after the timed region")
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes from this process even for --gpus 1 (N > 1 always does when not "
                          "already launched): exercises the launcher and the RCCL gather at world size 1")
     args = ap.parse_args()
+    if args.config:
+        args.model, args.dtype, args.batch = {1: ("b16", "f32", 256), 2: ("b16", "bf16", 2048), 3: ("b16", "bf16", 2048),
+                                              4: ("l16_384", "bf16", 1024)}[args.config]
     if args.lanes <= 0:
         args.lanes = 1 if args.dtype == "f32" else 2
 
@@ -192,6 +207,14 @@ def main() -> None:
     # CPU baseline sees the same bytes) and tiled on the device; resident in HBM before timing.
     n_distinct = min(B, 8)
     host_imgs = synth.make_images(cfg, n_distinct, seed=99 + 1000 * rank)
+    golden = None
+    if args.model == "b16" and B >= 2:
+        # images 0 and 1 of EVERY rank's batch are the two golden images (generated from the seed the fixture records; the
+        # fixture holds what the reference's own ViT_seq() made of them with the seed-1234 weights used above)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "vit_b16_e2e.npz"))
+        if int(g["weight_seed"]) == 1234:
+            golden = g["probs"].astype(np.float32)
+            host_imgs[:2] = synth.make_images(cfg, 2, seed=int(g["image_seed"]))
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         base = torch.from_numpy(host_imgs).to(dev)
@@ -230,12 +253,33 @@ def main() -> None:
     fence()
     dt = time.perf_counter() - t0
     gather_ok = None
+    tol = 1e-4 if args.dtype == "f32" else 2e-2
+    gold = None
+    if golden is not None:  # rows 0-1 of the timed steps' output against the reference's probabilities, on this rank
+        got2 = probs[:2].cpu().numpy()
+        gold = {"rows": 2, "max_abs_prob_err": float(np.abs(got2 - golden).max()),
+                "top1_match": bool((got2.argmax(1) == golden.argmax(1)).all()), "tolerance": tol}
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # the gathered records of this rank's slot must be this rank's own top-1 (checked outside the timed region)
-        gather_ok = bool(torch.equal(gathered[rank], top1))
+        # the gather, checked outside the timed region: EVERY slot r must hold what rank r says its records are (a broadcast
+        # per rank: another collective than the one under test), and -- the batches start with the golden images -- the
+        # golden labels in its first two entries
+        gather_ok = True
+        for r in range(world):
+            theirs = top1.clone()
+            dist.broadcast(theirs, src=r)
+            gather_ok = gather_ok and bool(torch.equal(gathered[r], theirs))
+            if golden is not None:
+                gather_ok = gather_ok and gathered[r, 0, :2].cpu().tolist() == golden.argmax(1).tolist()
+        flags = torch.tensor([1.0 if gather_ok else 0.0, -gold["max_abs_prob_err"] if gold else 0.0,
+                              1.0 if (gold is None or gold["top1_match"]) else 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)   # the worst of all ranks
+        gather_ok = bool(flags[0].item() == 1.0)
+        if gold:
+            gold.update(max_abs_prob_err=float(-flags[1].item()), top1_match=bool(flags[2].item() == 1.0), ranks=world)
+    handover = eng.handover_stats() if args.dtype == "f32" else None   # fp32 GEMM helper pieces of warm-up + timed steps
     kernel_steps = args.steps
     if args.lanes == 1 and not args.graph and not args.no_stage_brackets:
         times = eng.stage_times()
@@ -304,6 +348,9 @@ def main() -> None:
         "whole_model_tflops": round(model_tflops, 2),
         "whole_model_frac": round(model_tflops / peak, 4),
         "stage_ms_per_step": {s: round(r["ms"] / kernel_steps, 3) for s, r in times["stages"].items()},
+        # fp32 GEMM helper pieces over warm-up + timed steps: tiles finished from a parked piece / tiles whose owner found none
+        # and computed all of it (lost time, never a wrong result: nothing in the hand-over waits)
+        "gemm_handover": handover,
         "measured": ("HIP events around every launch during the timed steps" if (args.lanes == 1 and not args.graph and not args.no_stage_brackets) else
                      f"HIP events around every launch in {kernel_steps} extra steps with lanes=1 right after the timed region "
                      + (f"(the timed steps run {args.lanes} concurrent lanes, whose kernels overlap)" if args.lanes > 1 else
@@ -358,6 +405,36 @@ def main() -> None:
             cpu["all_cores"] = {"value": round(ncore / all_dt, 4), "unit": "images/sec", "cores": ncore,
                                 "sample": f"{ncore} concurrent single-threaded forwards (one image each), {all_dt:.2f} s"}
 
+    # ---- through the C surface (N = 1): host images in, host probability rows out ------------------
+    c_surface = None
+    if rank == 0 and world == 1 and not args.no_c_surface:
+        import ctypes as C
+        eng.set_profile(False)
+        eng.set_lanes(args.lanes)
+        host_batch = images.cpu().numpy()                  # the SAME batch, as B separately addressed host images
+        host_probs = np.empty((B, cfg.num_classes), np.float32)
+        in_ptrs = (binding.f32p * B)(*[host_batch[i].ctypes.data_as(binding.f32p) for i in range(B)])
+        out_ptrs = (binding.f32p * B)(*[host_probs[i].ctypes.data_as(binding.f32p) for i in range(B)])
+        reps = 3
+        best = None
+        for i in range(reps + 1):                          # the first call is a warm-up (pinned staging gets touched)
+            t3 = time.perf_counter()
+            rc = binding.lib().vit_engine_forward_host(eng._h, in_ptrs, B, out_ptrs)
+            d3 = time.perf_counter() - t3
+            if rc != 0:
+                sys.exit("bench.py: vit_engine_forward_host failed")
+            if i > 0:
+                best = d3 if best is None else min(best, d3)
+        same = bool(np.array_equal(host_probs, probs.cpu().numpy()))
+        c_surface = {"value": round(B / best, 2), "unit": "images/sec", "ms_per_call": round(1e3 * best, 3),
+                     "h2d_mb": round(host_batch.nbytes / 1e6, 1), "d2h_mb": round(host_probs.nbytes / 1e6, 3),
+                     "sample": f"best of {reps} calls of vit_engine_forward_host on the timed batch ({B} images, pageable host "
+                               "memory, pinned double-buffered staging inside the call)",
+                     "bit_identical_to_device_path": same}
+
+    ok = (gather_ok is not False) and (gold is None or (gold["top1_match"] and gold["max_abs_prob_err"] <= tol))
+    if parity is not None:
+        ok = ok and parity["top1_match"] and parity["max_abs_prob_err"] <= parity["tolerance"]
     if rank == 0:
         info = binding.device_info(local_rank)
         print(json.dumps({
@@ -367,16 +444,18 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": (f"{'ViT-B/16 224x224' if args.model == 'b16' else 'ViT-L/16 384x384'} "
                                     f"{'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} forward, batch {B} per GPU, synthetic weights and images "
-                                    "(BASELINE.json configs[%d])" % (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2))),
+                                    "(BASELINE.json configs[%d])" % (args.config or (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2)))),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                        "top1_gather": ("rccl all_gather, 8 B per image" + ("" if gather_ok else " (MISMATCH)")) if distributed else None,
                        "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "ln_fold": (args.ln_fold >= 0) if args.dtype == "bf16" else False, "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "golden": gold, "c_surface": c_surface, "ok": ok,
         }))
     eng.close()
     if distributed:
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

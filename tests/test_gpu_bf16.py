@@ -198,6 +198,35 @@ def test_bf16_forward_b16_vs_reference_golden(ln_fold):
     eng.close()
 
 
+def test_bf16_forward_b16_batch2048_position_invariance_and_golden():
+    """BASELINE.json configs[2] at its full size: 2,048 images, two lanes, LayerNorm fold on -- 1,576-row-tile persistent
+    ping-pong GEMMs and 12,288 (image, head) items per lane for the resident attention, shapes no 8-image test reaches.
+    The batch is 16 distinct images x 128 copies in a shuffled order: copies must give bit-identical rows wherever they sit
+    (any lane, any tile, any workgroup), rows sum to 1, and the two golden images inside still meet the bf16 bar against the
+    reference's fp32 probabilities.  The bf16 twin of test_b16_batch256_position_invariance_and_golden."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vit_b16_e2e.npz"))
+    cfg = synth.VIT_B16
+    n = 2048
+    base = synth.make_images(cfg, 16, int(g["image_seed"]))            # images 0, 1 are the golden ones
+    idx = (np.arange(n) % 16)[np.random.default_rng(2).permutation(n)]
+    eng = B.Engine(cfg, max_batch=n, dtype="bf16", lanes=2)
+    eng.load_weights(synth.make_weights(cfg, int(g["weight_seed"])))
+    d_in, d_out = B.DeviceArray.from_numpy(base[idx]), B.DeviceArray((n, cfg.num_classes))
+    eng.forward_device(d_in.ptr, n, d_out.ptr)                          # ONE chunk of 2,048 (what bench.py --config 2 times)
+    eng.sync()
+    probs = d_out.numpy()
+    eng.close()
+    for k in range(16):
+        rows = probs[idx == k]
+        assert (rows == rows[0]).all(), f"image {k}: rows differ with batch position"
+    assert np.allclose(probs.sum(1), 1.0, atol=1e-5)
+    for k in (0, 1):
+        row = probs[idx == k][0]
+        assert float(np.abs(row - g["probs"][k]).max()) <= BF16_PROB_TOL
+        assert int(row.argmax()) == int(g["probs"][k].argmax())
+
+
 def test_bf16_forward_vit_l_geometry(oracle, ln_fold):
     """ViT-L/16-384 width and sequence length (D=1024, 16 heads, H=4096, 577 tokens), 2 layers, bf16 GEMMs
     (K = 1024 / 4096) + the chunked attention with bf16 I/O, against the fp32 oracle."""

@@ -183,11 +183,11 @@ def test_concurrent_lanes_give_identical_results(b16, lanes):
     assert np.array_equal(got, ref)
 
 
-def _forward_device(eng, imgs):
+def _forward_device(eng, imgs, classes=1000):
     """One vit_engine_forward_device call on HBM-resident images: the whole batch is ONE chunk (the host-pointer path cuts a
     single chunk in two pieces to overlap its copies), i.e. the GEMM shapes bench.py times."""
     n = imgs.shape[0]
-    d_in, d_out = B.DeviceArray.from_numpy(imgs), B.DeviceArray((n, 1000))
+    d_in, d_out = B.DeviceArray.from_numpy(imgs), B.DeviceArray((n, classes))
     eng.forward_device(d_in.ptr, n, d_out.ptr)
     eng.sync()
     return d_out.numpy()
@@ -351,3 +351,14 @@ def test_vit_l16_384_full_depth_matches_oracle(oracle):
         assert err <= tol, dtype
         if dtype == "f32":
             assert lerr <= 1e-3
+        else:
+            # the configuration's own regime: 272 images = 4,352 (image, head) items for the streamed attention's 256
+            # persistent workgroups, 613 row-tiles for the ping-pong GEMMs, two lanes.  Copies of the two oracle-checked images
+            # scattered through the batch must come out exactly as in the 2-image run, wherever they sit.
+            n = 272
+            idx = (np.arange(n) % 2)[np.random.default_rng(3).permutation(n)]
+            big = B.Engine(cfg, max_batch=n, dtype="bf16", lanes=2)
+            big.load_weights(W)
+            got = _forward_device(big, imgs[idx], cfg.num_classes)
+            big.close()
+            assert np.array_equal(got, probs[idx]), "ViT-L/16-384 bf16: a row depends on the batch it is computed in"

@@ -116,6 +116,34 @@ def test_facade_with_two_engines_splits_the_image_loop():
     assert float(np.abs(single[:n_gold] - g["probs"][:n_gold]).max()) <= 1e-4
 
 
+def test_facade_on_all_devices_of_the_node():
+    """VIT_HIP_DEVICES=all on a node with several GPUs: one engine per physical device, the weights replicated device-to-device
+    (xGMI), image[0..n) cut into one contiguous slice per device.  Must reproduce the single-device result bit for bit.
+    Skipped on a 1-GPU box (the same code path is covered there by VIT_HIP_DEVICES=0,0 above)."""
+    import ctypes as C
+    n_dev = C.c_int()
+    B.hip_check(B.lib().vithip_device_count(C.byref(n_dev)), "vithip_device_count")
+    if n_dev.value < 2:
+        pytest.skip(f"needs >= 2 HIP devices, this box has {n_dev.value}")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "vit_b16_e2e.npz"))
+    cfg = synth.VIT_B16
+    W = synth.make_weights(cfg, int(g["weight_seed"]))
+    n = 2 * n_dev.value + 1                                # ragged: one device gets an extra image
+    imgs = synth.make_images(cfg, n, int(g["image_seed"]))
+    single = B.facade_forward(imgs, W)
+    os.environ["VIT_HIP_DEVICES"] = "all"
+    try:
+        L = B.lib()
+        L.initialize_opencl()
+        assert L.ViT_hip_device_count() == n_dev.value
+        L.Release_opencl()
+        got = B.facade_forward(imgs, W)
+    finally:
+        del os.environ["VIT_HIP_DEVICES"]
+    assert np.array_equal(got, single)
+    assert float(np.abs(single[:2] - g["probs"][:2]).max()) <= 1e-4
+
+
 def test_fp32_chunk_is_capped_below_2gib_per_launch():
     """ViT-L/16-384 fp32: one image's MLP hidden rows are 9.45 MB, so 227 images fill the 2 GiB a buffer descriptor
     addresses (max_batch 256 used to fail mid-layer with hipErrorInvalidValue).  The engine now cuts the chunk."""
@@ -147,6 +175,23 @@ def test_bench_rank_takes_the_rccl_path_at_world_size_one():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["top1_gather"] == "rccl all_gather, 8 B per image"
     assert rec["value"] > 0
+    # the line validates itself: golden rows inside the timed batch, every gather slot checked, the host-pointer surface
+    assert rec["ok"] is True
+    assert rec["golden"]["top1_match"] and rec["golden"]["max_abs_prob_err"] <= 1e-4 and rec["golden"]["ranks"] == 1
+    assert rec["c_surface"]["bit_identical_to_device_path"] and rec["c_surface"]["value"] > 0
+    assert rec["roofline"]["gemm_handover"] is not None
+
+
+def test_bench_config3_preset_is_bf16_2048_per_gpu():
+    """--config 3 = BASELINE.json configs[3]'s per-GPU shape (bf16, 2,048 images per GPU); the bf16 line carries the golden
+    parity block too (2e-2, identical top-1), measured on the timed batch itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VIT_LAUNCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-c-surface"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["dtype"] == "bf16" and rec["config"]["batch_per_gpu"] == 2048 and "configs[3]" in rec["config"]["workload"]
+    assert rec["ok"] is True and rec["golden"]["top1_match"] and rec["golden"]["max_abs_prob_err"] <= 2e-2
 
 
 @pytest.mark.parametrize("n_images", [6, 5])

@@ -19,6 +19,7 @@
 
 #include <type_traits>
 
+#include "vit_device.hpp"
 #include "vit_hip_kernels.h"
 #ifdef VIT_PROBES
 #include "vit_probes.h"
@@ -775,12 +776,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(con
 template <int NKT>
 int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads, int q_rows) {
     const int items = heads * n_images;
-    static int cus = 0;  // CU count, queried once
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return static_cast<int>(hipErrorInvalidDevice);
-    }
+    const int cus = vitdev::current_cus();
+    if (cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     const int per_cu = NKT <= 3 ? 2 : 1;  // VGPR-limited residency (8 waves per workgroup)
     const int grid = items < cus * per_cu ? items : cus * per_cu;
     hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(grid), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads, items, q_rows);

@@ -34,6 +34,7 @@
 
 #include <type_traits>
 
+#include "vit_device.hpp"
 #include "vit_hip_kernels.h"
 
 namespace vitattn {
@@ -552,13 +553,8 @@ int launch_resident(hipStream_t s, const float *qkv, float *out, int n_images, i
 
 // tokens <= 224, q_rows <= tokens.  Returns a hipError_t value.
 int attention_f32_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows) {
-    static int cus = 0;  // every device of a node is the same part
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return static_cast<int>(hipErrorInvalidDevice);
-        cus = v;
-    }
+    const int cus = vitdev::current_cus();
+    if (cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     switch ((tokens + 15) / 16) {
         case 1: return launch_resident<1>(s, qkv, out, n_images, tokens, heads, q_rows, cus);
         case 2: return launch_resident<2>(s, qkv, out, n_images, tokens, heads, q_rows, cus);

@@ -22,6 +22,7 @@
 
 #include <type_traits>
 
+#include "vit_device.hpp"
 #include "vit_hip_kernels.h"
 
 namespace vitattn {
@@ -407,22 +408,18 @@ unsigned long long *g_stream_dbg = nullptr;
 
 // 224 < tokens <= 704 (the head's Q blocks share the LDS with the K/V ring).  Returns a hipError_t value.
 int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return static_cast<int>(hipErrorInvalidDevice);
-        cus = v;
-    }
+    int dev = 0;
+    const int cus = vitdev::current_cus(&dev);
+    if (cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     const int nblk = (tokens + 31) / 32;
     const size_t lds_bytes = (size_t)(2 * SBUF + nblk * 32 * SHD) * sizeof(bf16_t);  // ring + the head's Q blocks
     if (tokens > ST_WAVES * MAXB * 32 || lds_bytes > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static vitdev::PerDeviceOnce attr_set;  // the attribute belongs to this device's copy of the kernel
+    if (!attr_set.is_done(dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bf16_stream_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return static_cast<int>(e);
-        attr_set = true;
+        attr_set.set(dev);
     }
     const int items = n_images * heads;
     const int grid = items < cus ? items : cus;

@@ -23,6 +23,7 @@
 //    and 4 consecutive columns n per register group, so the epilogue packs 4 bf16 (8 B) or one float4 per
 //    store instead of scattering 2-byte elements.
 //  * Tile walk: XCD-aware remap + groups of 8 tile rows (as the fp32 kernel).
+#include "vit_device.hpp"
 #include "vit_gemm_common.hpp"
 #ifdef VIT_PROBES
 #include "vit_probes.h"
@@ -301,7 +302,6 @@ __global__ void cls_rows_bf16path_kernel(const float *cls, const float *pos, flo
 }
 
 bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
-int g_cus = 0;      // CU count, queried once (every device of a node is the same part)
 // Kernel variant, barrier schedule and start-up skew are per-call fields of vithip_gemm_bf16_args; the product library
 // has no mutable process-wide state.  The probe build (-DVIT_PROBES) adds process-wide overrides and instrumented kernels.
 #ifdef VIT_PROBES
@@ -386,11 +386,8 @@ int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const u
     p.patches = P;
     p.stagger = 0;
     p.sync1 = 1;
-    if (g_cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return static_cast<int>(hipErrorInvalidDevice);
-    }
+    const int g_cus = vitdev::current_cus();  // of the current device, asked per call (engines of several devices share the process)
+    if (g_cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     return vitgemm::launch_gemm_bf16_pp(s, p, VITHIP_BF16_EPI_F32_EMBED, g_cus);
 }
 
@@ -451,11 +448,8 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     if (g_stagger >= 0) p.stagger = g_stagger;
     if (g_sync1 >= 0) p.sync1 = g_sync1;
 #endif
-    if (g_cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return static_cast<int>(hipErrorInvalidDevice);
-    }
+    const int g_cus = vitdev::current_cus();  // of the current device, asked per call (engines of several devices share the process)
+    if (g_cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     const int total = p.tiles_m * p.tiles_n;
     const dim3 grid(total < g_cus ? total : g_cus), block(THREADS);  // one persistent workgroup per CU
     hipStream_t s = static_cast<hipStream_t>(stream);
