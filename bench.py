@@ -48,15 +48,23 @@ STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it at the met
 }
 
 
-PROFILE_ROUND = "r02"   # profiles/<round>/: the committed rocprofv3 passes the replayed counter fields come from
+PROFILE_ROUND = "r03"   # profiles/<round>/: the committed rocprofv3 passes the replayed counter fields come from
 
 
-def pmc_traffic(kernel, dtype, batch):
+def profile_tag(dtype, model):
+    """Suffix of the committed profile files for a bench configuration: f32 | bf16 | bf16_l16_384 (configs[1], [2], [4])."""
+    return dtype if model == "b16" else f"{dtype}_{model}"
+
+
+PROFILED_BATCH = {"f32": 256, "bf16": 2048, "bf16_l16_384": 1024}   # the batch each set of passes was collected at
+
+
+def pmc_traffic(kernel, tag, batch):
     """(HBM bytes per launch of `kernel`, provenance) from the committed PMC passes (profiles/<round>/README.md: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, summarised by tools/pmc_summary.py).
     NOT collected live -- counters need the profiler -- so the value is a replay and says so (roofline.replayed_from).
     (None, None) when the passes do not cover this configuration."""
-    rel = os.path.join("profiles", PROFILE_ROUND, f"hbm_traffic_pmc_{dtype}.json")
+    rel = os.path.join("profiles", PROFILE_ROUND, f"hbm_traffic_pmc_{tag}.json")
     try:
         with open(os.path.join(ROOT, rel)) as f:
             rec = json.load(f)
@@ -83,18 +91,18 @@ def quiet_stdout(fn):
         os.close(devnull)
 
 
-def pmc_mfma(kernel, dtype, batch):
-    """(MFMA-busy %, clock GHz) of `kernel` from the committed rocprofv3 PMC pass (profiles/r01/mfma_util_<dtype>.csv,
+def pmc_mfma(kernel, tag, batch):
+    """(MFMA-busy %, clock GHz) of `kernel` from the committed rocprofv3 PMC pass (profiles/<round>/mfma_util_<tag>.csv,
     tools/collect_profiles.sh); (None, None) when that pass does not cover this configuration."""
     import csv
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         from pmc_summary import bench_key
-        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, f"mfma_util_{dtype}.csv"), newline="") as f:
+        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, f"mfma_util_{tag}.csv"), newline="") as f:
             rows = [r for r in csv.DictReader(f) if bench_key(r["kernel"]) == kernel]
     except (OSError, ImportError):
         return None, None
-    if not rows or batch != (256 if dtype == "f32" else 2048):
+    if not rows or batch != PROFILED_BATCH.get(tag):
         return None, None
     r = max(rows, key=lambda r: float(r["avg_us"]) * int(r["launches"]))
     return float(r["mfma_busy_percent"]), float(r["clock_ghz_from_gui_active"])
@@ -313,6 +321,8 @@ def main() -> None:
         k = STAGE_KERNEL[stage]
         if args.dtype == "bf16" and stage == "embed":
             k = "gemm_bf16_pp_kernel<F32_EMBED>"
+        if args.dtype == "bf16" and stage == "attn":
+            k = "attention_bf16_kernel" if cfg.tokens <= 224 else "attention_bf16_stream_kernel"
         if args.dtype == "bf16" and stage in ("qkv", "outproj", "fc1", "fc2"):
             k = "gemm_bf16_pp_kernel<%s>" % {"qkv": "BF16", "fc1": "BF16_GELU", "outproj": "F32_RESIDUAL", "fc2": "F32_RESIDUAL"}[stage]
         d = per_kernel.setdefault(k, {"ms": 0.0, "launches": 0, "flop": 0.0})
@@ -327,14 +337,15 @@ def main() -> None:
     achieved = dom["flop"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     gemm_ms = sum(v["ms"] for k, v in per_kernel.items() if k.startswith("gemm"))
     gemm_flop = sum(v["flop"] for k, v in per_kernel.items() if k.startswith("gemm"))
-    traffic, traffic_src = pmc_traffic(dom_name, args.dtype, B)
-    busy, clock = pmc_mfma(dom_name, args.dtype, B)
+    tag = profile_tag(args.dtype, args.model)
+    traffic, traffic_src = pmc_traffic(dom_name, tag, B)
+    busy, clock = pmc_mfma(dom_name, tag, B)
     replayed = None
     if traffic_src or busy is not None:
         # counter-derived fields cannot be read without the profiler: they are REPLAYED from the committed rocprofv3
         # passes of this same command (another run, possibly another device of the pool) -- everything else in this
         # object is measured live in this process
-        replayed = dict(traffic_src or {"path": os.path.join("profiles", PROFILE_ROUND, f"mfma_util_{args.dtype}.csv")},
+        replayed = dict(traffic_src or {"path": os.path.join("profiles", PROFILE_ROUND, f"mfma_util_{tag}.csv")},
                         fields=[k for k, v in (("traffic", traffic), ("mfma_busy_percent_rocprof", busy),
                                                ("clock_ghz_rocprof", clock)) if v is not None],
                         live=False)

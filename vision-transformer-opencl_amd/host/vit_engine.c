@@ -543,292 +543,333 @@ static int collect_profile(vit_engine *e) {
  * With opt.lanes > 1 the chunk is cut into that many sub-batches that run the same stage sequence
  * on their own HIP streams (lane 0 on the caller's stream, which forks and joins the others with
  * events).  The sub-batches are independent -- images never interact -- so this adds no
- * synchronisation to the data path; what it buys is that the tail of one lane's GEMM (a partial
- * last round of tiles: 2364 tiles on 512 workgroup slots = 4.6 rounds for the N = 768 layers) and
- * its low-occupancy kernels are filled by the other lane's workgroups instead of idling the CUs.
- * Launches are issued stage by stage across the lanes so that the queues advance together.
+ * synchronisation to the data path; what it buys is that the low-occupancy and HBM-bound kernels of
+ * one lane run beside the other lane's GEMMs.  Launches are issued stage by stage across the lanes so
+ * that the queues advance together.
+ *
+ * The layer loop picks ONE of six layer bodies (fp32 / bf16 with LayerNorm kernels / bf16 with the
+ * LayerNorm fold, each in its full and its class-rows-only "pruned last layer" form); every body is a
+ * sequence of stages, each stage issued for every lane.
  */
 typedef struct {
     vithip_stream_t s;
     int off, n; /* first image of the lane inside the chunk, image count */
 } vit_lane;
 
-static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images, int nb, float *d_probs,
-                         int *d_label, float *d_prob) {
-    const vit_config *c = &e->cfg;
-    const int T = e->tokens, D = c->embed_dim, H = c->hidden_dim, NC = c->num_classes;
-    const size_t img = (size_t)c->in_chans * c->img_size * c->img_size;
-    float **w = e->w;
-    int rc;
-
+typedef struct {
+    vit_engine *e;
     vit_lane lane[VIT_MAX_LANES];
-    int L = e->opt.lanes;
-    if (L > VIT_MAX_LANES) L = VIT_MAX_LANES;
-    if (L < 1 || nb < 2 * L) L = 1;
-    for (int j = 0; j < L; ++j) {
-        lane[j].off = (int)((long)nb * j / L);
-        lane[j].n = (int)((long)nb * (j + 1) / L) - lane[j].off;
-        lane[j].s = j == 0 ? s : e->aux_stream[j - 1];
-    }
-    if (L > 1) { /* fork: the other lanes start after everything already queued on s */
-        HIP_TRY(e, vithip_event_record(e->ev_fork, s));
-        for (int j = 1; j < L; ++j) HIP_TRY(e, vithip_stream_wait_event(lane[j].s, e->ev_fork));
-    }
+    int L;                       /* lanes in use for this chunk */
+    int T, D, H, NC;
+    /* bf16 views of the activation buffers (bf16 activations half fill the fp32-sized allocations) */
+    unsigned short *y16, *qkv16, *h16;
+    /* LayerNorm fold scratch, in the idle halves: bf16 copy of x (y allocation); row sums, (rstd, mean*rstd) pairs per token
+     * and -- pruned last layer -- per class row (qkv allocation).  A lane uses its own rows of each. */
+    unsigned short *x16;
+    float *ln_part, *ln_rows, *cls_rows;
+    int strips;
+} chunk_ctx;
 
-#define LANES for (int j = 0; j < L; ++j)
-#define ROWS(j) ((size_t)lane[j].off * T)
-    const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
+#define LANES for (int j = 0; j < c->L; ++j)
+#define LN_ (c->lane[j])
+#define ROWS(j) ((size_t)c->lane[j].off * c->T)
+#define PART(j) (c->ln_part + ROWS(j) * (size_t)c->strips * 2)
+#define RUN(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+/* conv_proj + flatten_transpose + class_token + pos_emb (ViT_seq.c:25-101) */
+static int stage_embed(chunk_ctx *c, const float *d_images) {
+    vit_engine *e = c->e;
+    const vit_config *cfg = &e->cfg;
+    float **w = e->w;
+    const size_t img = (size_t)cfg->in_chans * cfg->img_size * cfg->img_size;
     /* bf16 patch embedding needs K = chans*patch^2 to be a multiple of 64 (two K steps at least) and patch % 8 == 0;
      * its bf16 patch rows live in the (still unused) hidden-layer buffer */
-    const int pk = c->in_chans * c->patch_size * c->patch_size;
-    const int embed16 = bf16 && pk % 64 == 0 && pk >= 128 && c->patch_size % 8 == 0 && (size_t)pk <= 2 * (size_t)H;
+    const int pk = cfg->in_chans * cfg->patch_size * cfg->patch_size;
+    const int embed16 = e->opt.dtype == VIT_DTYPE_BF16 && pk % 64 == 0 && pk >= 128 && cfg->patch_size % 8 == 0 &&
+                        (size_t)pk <= 2 * (size_t)c->H;
     LANES {
-        HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_EMBED));
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_EMBED));
         if (embed16)
-            HIP_TRY(e, vithip_patch_embed_bf16(lane[j].s, d_images + lane[j].off * img, e->w16[1], w[2], w[0], w[3],
-                                               e->x + ROWS(j) * D, (unsigned short *)e->hbuf + (size_t)lane[j].off * (T - 1) * pk,
-                                               lane[j].n, c->img_size, c->patch_size, c->in_chans, D));
+            HIP_TRY(e, vithip_patch_embed_bf16(LN_.s, d_images + LN_.off * img, e->w16[1], w[2], w[0], w[3],
+                                               e->x + ROWS(j) * c->D, (unsigned short *)e->hbuf + (size_t)LN_.off * (c->T - 1) * pk,
+                                               LN_.n, cfg->img_size, cfg->patch_size, cfg->in_chans, c->D));
         else
-            HIP_TRY(e, vithip_patch_embed_f32(lane[j].s, d_images + lane[j].off * img, w[1], w[2], w[0], w[3],
-                                              e->x + ROWS(j) * D, lane[j].n, c->img_size, c->patch_size, c->in_chans, D));
-        HIP_TRY(e, stage_end(e, lane[j].s));
+            HIP_TRY(e, vithip_patch_embed_f32(LN_.s, d_images + LN_.off * img, w[1], w[2], w[0], w[3],
+                                              e->x + ROWS(j) * c->D, LN_.n, cfg->img_size, cfg->patch_size, cfg->in_chans, c->D));
+        HIP_TRY(e, stage_end(e, LN_.s));
     }
-    /* bf16 variant: LN output, qkv, attention output and the MLP hidden layer are bf16 (they live in the same
-     * allocations, half used); the residual stream x, LayerNorm statistics, softmax and every accumulation
-     * stay fp32; patch embedding and the classifier head run the fp32 kernels. */
-    unsigned short *y16 = (unsigned short *)e->y, *qkv16 = (unsigned short *)e->qkv, *h16 = (unsigned short *)e->hbuf;
-    /* prune_last_layer: see vit_engine_options.  The class rows of a [n*T][D] buffer are rows 0, T, 2T, ... = a matrix
-     * with leading dimension T*D, which every op here takes as it is. */
-    const int prune = e->opt.prune_last_layer && T <= 224;
-    /* LayerNorm fold (e->fold): the bf16 copy of x lives in the idle half of the y allocation, the row sums and the
-     * (rstd, mean*rstd) pairs in the idle half of the qkv allocation; a lane uses its own rows of each. */
-    const int strips = vithip_ln_strips((int)D);
-    unsigned short *x16 = y16 + (size_t)e->opt.max_batch * T * D;
-    float *ln_part = (float *)(qkv16 + (size_t)e->opt.max_batch * T * 3 * D);
-    float *ln_rows = ln_part + (size_t)strips * e->opt.max_batch * T * 2;
-    float *cls_rows = ln_rows + (size_t)e->opt.max_batch * T * 2; /* pruned last layer: the pairs of the class rows, compact */
-#define PART(j) (ln_part + ROWS(j) * (size_t)strips * 2)
-    for (int l = 0; l < c->depth && bf16; ++l) {
-        float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
+    return VIT_OK;
+}
+
+/* ---- fp32 layer (the reference's arithmetic, ViT_seq.c:276-300) ---- */
+static int layer_f32(chunk_ctx *c, float **lw) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    LANES { /* LN1 (ViT_seq.c:281) */
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(LN_.s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D, lw[0], lw[1], LN_.n * T, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES /* QKV in_proj (ViT_seq.c:134-147) */
+        RUN(gemm(e, LN_.s, VIT_STAGE_QKV, e->y + ROWS(j) * D, D, lw[2], lw[3], NULL, e->qkv + ROWS(j) * 3 * D, 3 * D, LN_.n * T, 3 * D, D, VITHIP_EPI_BIAS));
+    LANES { /* scores, softmax, P.V (ViT_seq.c:156-215) -> y */
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_f32(LN_.s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, LN_.n, T, heads));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES /* out_proj + residual (ViT_seq.c:219-227,286-288): x = x + (y.Wo^T + bo) */
+        RUN(gemm(e, LN_.s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, D, lw[4], lw[5], e->x + ROWS(j) * D, e->x + ROWS(j) * D, D, LN_.n * T, D, D, VITHIP_EPI_BIAS_RESIDUAL));
+    LANES { /* LN2 (ViT_seq.c:291) */
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(LN_.s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D, lw[6], lw[7], LN_.n * T, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES /* fc1 + GELU (ViT_seq.c:258-264) */
+        RUN(gemm(e, LN_.s, VIT_STAGE_FC1, e->y + ROWS(j) * D, D, lw[8], lw[9], NULL, e->hbuf + ROWS(j) * H, H, LN_.n * T, H, D, VITHIP_EPI_BIAS_GELU));
+    LANES /* fc2 + residual (ViT_seq.c:266,297-299): x = x + (h.W2^T + b2) */
+        RUN(gemm(e, LN_.s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, D, LN_.n * T, D, H, VITHIP_EPI_BIAS_RESIDUAL));
+    return VIT_OK;
+}
+
+/* prune_last_layer (vit_engine_options): K and V of every token, everything else for the class rows only.  The class rows of a
+ * [n*T][D] buffer are rows 0, T, 2T, ... = a matrix with leading dimension T*D, which every operator takes as it is. */
+static int layer_f32_pruned(chunk_ctx *c, float **lw) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(LN_.s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D, lw[0], lw[1], LN_.n * T, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES { /* K and V of every token (in_proj rows D..3D), Q of the class rows only */
+        RUN(gemm(e, LN_.s, VIT_STAGE_QKV, e->y + ROWS(j) * D, D, lw[2] + (size_t)D * D, lw[3] + D, NULL, e->qkv + ROWS(j) * 3 * D + D, 3 * D, LN_.n * T, 2 * D, D, VITHIP_EPI_BIAS));
+        RUN(gemm(e, LN_.s, VIT_STAGE_QKV, e->y + ROWS(j) * D, T * D, lw[2], lw[3], NULL, e->qkv + ROWS(j) * 3 * D, T * 3 * D, LN_.n, D, D, VITHIP_EPI_BIAS));
+    }
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_f32_rows(LN_.s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, LN_.n, T, heads, 1));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm(e, LN_.s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, T * D, lw[4], lw[5], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, D, VITHIP_EPI_BIAS_RESIDUAL));
+    LANES { /* LN2 of the class rows -> compact [n][D] at the head of the lane's y region */
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(LN_.s, e->x + ROWS(j) * D, (size_t)T * D, e->y + ROWS(j) * D, (size_t)D, lw[6], lw[7], LN_.n, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm(e, LN_.s, VIT_STAGE_FC1, e->y + ROWS(j) * D, D, lw[8], lw[9], NULL, e->hbuf + ROWS(j) * H, H, LN_.n, H, D, VITHIP_EPI_BIAS_GELU));
+    LANES
+        RUN(gemm(e, LN_.s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, H, VITHIP_EPI_BIAS_RESIDUAL));
+    return VIT_OK;
+}
+
+/* ---- bf16 layer with LayerNorm kernels: LN output, qkv, attention output and the MLP hidden layer are bf16; the residual
+ * stream x, LayerNorm statistics, softmax and every accumulation stay fp32 ---- */
+static int layer_bf16(chunk_ctx *c, float **lw, unsigned short **lw16) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32_bf16out(LN_.s, e->x + ROWS(j) * D, (size_t)D, c->y16 + ROWS(j) * D, (size_t)D, lw[0], lw[1], LN_.n * T, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_QKV, c->y16 + ROWS(j) * D, D, lw16[2], lw[3], NULL, c->qkv16 + ROWS(j) * 3 * D, 3 * D, LN_.n * T, 3 * D, D, VITHIP_BF16_EPI_BF16));
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_bf16io(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_OUTPROJ, c->y16 + ROWS(j) * D, D, lw16[4], lw[5], e->x + ROWS(j) * D, e->x + ROWS(j) * D, D, LN_.n * T, D, D, VITHIP_BF16_EPI_F32_RESIDUAL));
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32_bf16out(LN_.s, e->x + ROWS(j) * D, (size_t)D, c->y16 + ROWS(j) * D, (size_t)D, lw[6], lw[7], LN_.n * T, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_FC1, c->y16 + ROWS(j) * D, D, lw16[8], lw[9], NULL, c->h16 + ROWS(j) * H, H, LN_.n * T, H, D, VITHIP_BF16_EPI_BF16_GELU));
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_FC2, c->h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, D, LN_.n * T, D, H, VITHIP_BF16_EPI_F32_RESIDUAL));
+    return VIT_OK;
+}
+
+static int layer_bf16_pruned(chunk_ctx *c, float **lw, unsigned short **lw16) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32_bf16out(LN_.s, e->x + ROWS(j) * D, (size_t)D, c->y16 + ROWS(j) * D, (size_t)D, lw[0], lw[1], LN_.n * T, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES { /* K and V of every token (in_proj rows D..3D), Q of the class rows only */
+        RUN(gemm16(e, LN_.s, VIT_STAGE_QKV, c->y16 + ROWS(j) * D, D, lw16[2] + (size_t)D * D, lw[3] + D, NULL, c->qkv16 + ROWS(j) * 3 * D + D, 3 * D, LN_.n * T, 2 * D, D, VITHIP_BF16_EPI_BF16));
+        RUN(gemm16(e, LN_.s, VIT_STAGE_QKV, c->y16 + ROWS(j) * D, T * D, lw16[2], lw[3], NULL, c->qkv16 + ROWS(j) * 3 * D, T * 3 * D, LN_.n, D, D, VITHIP_BF16_EPI_BF16));
+    }
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_bf16io_rows(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, 1));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_OUTPROJ, c->y16 + ROWS(j) * D, T * D, lw16[4], lw[5], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, D, VITHIP_BF16_EPI_F32_RESIDUAL));
+    LANES { /* LN2 of the class rows -> compact [n][D] at the head of the lane's y region */
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32_bf16out(LN_.s, e->x + ROWS(j) * D, (size_t)T * D, c->y16 + ROWS(j) * D, (size_t)D, lw[6], lw[7], LN_.n, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_FC1, c->y16 + ROWS(j) * D, D, lw16[8], lw[9], NULL, c->h16 + ROWS(j) * H, H, LN_.n, H, D, VITHIP_BF16_EPI_BF16_GELU));
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_FC2, c->h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, H, VITHIP_BF16_EPI_F32_RESIDUAL));
+    return VIT_OK;
+}
+
+/* ---- bf16 layer with the LayerNorm fold (vit_hip_kernels.h, "LayerNorm folding"): in_proj and fc1 read the raw bf16 rows x16
+ * with the gamma/beta-folded operands (f16 / ff) and the per-row (rstd, mean*rstd) pairs; out_proj and fc2 store bf16(x) and
+ * the row sums for the LayerNorm behind them.  `first`: layer 0, whose LN1 has no residual GEMM in front; `feeds_next`: fc2's
+ * output is read by another folded layer. ---- */
+static int layer_bf16_folded(chunk_ctx *c, float **lw, unsigned short **lw16, const unsigned short *f16, const float *ff, int first, int feeds_next) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    if (first)
+        LANES { /* one pass for bf16(x) and the row pairs */
+            HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+            HIP_TRY(e, vithip_rowstats_bf16(LN_.s, e->x + ROWS(j) * D, (size_t)D, c->x16 + ROWS(j) * D, (size_t)D, c->ln_rows + ROWS(j) * 2, LN_.n * T, D));
+            HIP_TRY(e, stage_end(e, LN_.s));
+        }
+    LANES /* LN1 + in_proj */
+        RUN(gemm16_ln(e, LN_.s, VIT_STAGE_QKV, c->x16 + ROWS(j) * D, D, f16, ff + 3 * D, ff, c->ln_rows + ROWS(j) * 2, c->qkv16 + ROWS(j) * 3 * D, 3 * D, LN_.n * T, 3 * D, D, VITHIP_BF16_EPI_BF16));
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_bf16io(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES /* out_proj + residual; bf16(x) and row sums for LN2 */
+        RUN(gemm16_res_stats(e, LN_.s, VIT_STAGE_OUTPROJ, c->y16 + ROWS(j) * D, D, lw16[4], lw[5], e->x + ROWS(j) * D, c->x16 + ROWS(j) * D, D, PART(j), c->ln_rows + ROWS(j) * 2, LN_.n * T, D, D));
+    LANES /* LN2 + fc1 + GELU */
+        RUN(gemm16_ln(e, LN_.s, VIT_STAGE_FC1, c->x16 + ROWS(j) * D, D, f16 + 3 * (size_t)D * D, ff + 6 * D + H, ff + 6 * D, c->ln_rows + ROWS(j) * 2, c->h16 + ROWS(j) * H, H, LN_.n * T, H, D, VITHIP_BF16_EPI_BF16_GELU));
+    LANES { /* fc2 + residual; bf16(x) and row sums for the next layer's LN1 */
+        if (feeds_next)
+            RUN(gemm16_res_stats(e, LN_.s, VIT_STAGE_FC2, c->h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D, c->x16 + ROWS(j) * D, D, PART(j), c->ln_rows + ROWS(j) * 2, LN_.n * T, D, H));
+        else
+            RUN(gemm16(e, LN_.s, VIT_STAGE_FC2, c->h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, D, LN_.n * T, D, H, VITHIP_BF16_EPI_F32_RESIDUAL));
+    }
+    return VIT_OK;
+}
+
+/* the sequence of layer_bf16_pruned in folded form: class rows = rows 0, T, 2T, ... */
+static int layer_bf16_folded_pruned(chunk_ctx *c, float **lw, unsigned short **lw16, const unsigned short *f16, const float *ff, int first) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    if (first)
+        LANES {
+            HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+            HIP_TRY(e, vithip_rowstats_bf16(LN_.s, e->x + ROWS(j) * D, (size_t)D, c->x16 + ROWS(j) * D, (size_t)D, c->ln_rows + ROWS(j) * 2, LN_.n * T, D));
+            HIP_TRY(e, stage_end(e, LN_.s));
+        }
+    LANES { /* K and V of every token (folded in_proj rows D..3D); Q of the class rows, whose (rstd, mean*rstd) pairs are copied
+             * out of the per-token array first */
+        float *cls = c->cls_rows + (size_t)LN_.off * 2;
+        RUN(gemm16_ln(e, LN_.s, VIT_STAGE_QKV, c->x16 + ROWS(j) * D, D, f16 + (size_t)D * D, ff + 3 * D + D, ff + D, c->ln_rows + ROWS(j) * 2, c->qkv16 + ROWS(j) * 3 * D + D, 3 * D, LN_.n * T, 2 * D, D, VITHIP_BF16_EPI_BF16));
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_gather_rows_f32(LN_.s, c->ln_rows + ROWS(j) * 2, (size_t)T * 2, cls, 2, LN_.n, 2));
+        HIP_TRY(e, stage_end(e, LN_.s));
+        RUN(gemm16_ln(e, LN_.s, VIT_STAGE_QKV, c->x16 + ROWS(j) * D, T * D, f16, ff + 3 * D, ff, cls, c->qkv16 + ROWS(j) * 3 * D, T * 3 * D, LN_.n, D, D, VITHIP_BF16_EPI_BF16));
+    }
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_bf16io_rows(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, 1));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm16_res_stats(e, LN_.s, VIT_STAGE_OUTPROJ, c->y16 + ROWS(j) * D, T * D, lw16[4], lw[5], e->x + ROWS(j) * D, c->x16 + ROWS(j) * D, T * D, PART(j), c->cls_rows + (size_t)LN_.off * 2, LN_.n, D, D));
+    LANES
+        RUN(gemm16_ln(e, LN_.s, VIT_STAGE_FC1, c->x16 + ROWS(j) * D, T * D, f16 + 3 * (size_t)D * D, ff + 6 * D + H, ff + 6 * D, c->cls_rows + (size_t)LN_.off * 2, c->h16 + ROWS(j) * H, H, LN_.n, H, D, VITHIP_BF16_EPI_BF16_GELU));
+    LANES
+        RUN(gemm16(e, LN_.s, VIT_STAGE_FC2, c->h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, H, VITHIP_BF16_EPI_F32_RESIDUAL));
+    return VIT_OK;
+}
+
+/* final LayerNorm on the class-token rows only (ViT_seq.c:429-433 normalises all rows, uses row 0), classifier head
+ * (ViT_seq.c:435), Softmax (ViT_seq.c:437) + top-1 (Main.c:62-70) */
+static int stage_head(chunk_ctx *c, float *d_probs, int *d_label, float *d_prob) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, NC = c->NC;
+    float **fw = e->w + 4 + VIT_WEIGHTS_PER_LAYER * e->cfg.depth;
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_layernorm_f32(LN_.s, e->x + ROWS(j) * D, (size_t)T * D, e->z + (size_t)LN_.off * D, (size_t)D, fw[0], fw[1], LN_.n, D));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm(e, LN_.s, VIT_STAGE_HEAD, e->z + (size_t)LN_.off * D, D, fw[2], fw[3], NULL, e->logits + (size_t)LN_.off * NC, NC, LN_.n, NC, D, VITHIP_EPI_BIAS));
+    LANES {
+        const size_t o = (size_t)LN_.off;
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_SOFTMAX));
+        HIP_TRY(e, vithip_softmax_top1_f32(LN_.s, e->logits + o * NC, NC, d_probs + o * NC, NC, d_label ? d_label + o : NULL, d_prob ? d_prob + o : NULL, LN_.n, NC));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    return VIT_OK;
+}
+
+static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images, int nb, float *d_probs,
+                         int *d_label, float *d_prob) {
+    const vit_config *cfg = &e->cfg;
+    chunk_ctx ctx, *c = &ctx;
+    c->e = e;
+    c->T = e->tokens; c->D = cfg->embed_dim; c->H = cfg->hidden_dim; c->NC = cfg->num_classes;
+    c->L = e->opt.lanes > VIT_MAX_LANES ? VIT_MAX_LANES : e->opt.lanes;
+    if (c->L < 1 || nb < 2 * c->L) c->L = 1;
+    for (int j = 0; j < c->L; ++j) {
+        c->lane[j].off = (int)((long)nb * j / c->L);
+        c->lane[j].n = (int)((long)nb * (j + 1) / c->L) - c->lane[j].off;
+        c->lane[j].s = j == 0 ? s : e->aux_stream[j - 1];
+    }
+    const size_t B = (size_t)e->opt.max_batch, T = (size_t)c->T, D = (size_t)c->D, H = (size_t)c->H;
+    c->y16 = (unsigned short *)e->y; c->qkv16 = (unsigned short *)e->qkv; c->h16 = (unsigned short *)e->hbuf;
+    c->strips = vithip_ln_strips((int)D);
+    c->x16 = c->y16 + B * T * D;
+    c->ln_part = (float *)(c->qkv16 + B * T * 3 * D);
+    c->ln_rows = c->ln_part + (size_t)c->strips * B * T * 2;
+    c->cls_rows = c->ln_rows + B * T * 2;
+
+    if (c->L > 1) { /* fork: the other lanes start after everything already queued on s */
+        HIP_TRY(e, vithip_event_record(e->ev_fork, s));
+        for (int j = 1; j < c->L; ++j) HIP_TRY(e, vithip_stream_wait_event(c->lane[j].s, e->ev_fork));
+    }
+    RUN(stage_embed(c, d_images));
+    const int bf16 = e->opt.dtype == VIT_DTYPE_BF16;
+    const int prune = e->opt.prune_last_layer && c->T <= 224;
+    for (int l = 0; l < cfg->depth; ++l) {
+        float **lw = e->w + 4 + VIT_WEIGHTS_PER_LAYER * l;
         unsigned short **lw16 = e->w16 + 4 + VIT_WEIGHTS_PER_LAYER * l;
-        const int last_pruned = prune && l == c->depth - 1;
-        if (e->fold) {
+        const int last_pruned = prune && l == cfg->depth - 1;
+        if (!bf16) {
+            RUN(last_pruned ? layer_f32_pruned(c, lw) : layer_f32(c, lw));
+        } else if (e->fold) {
             const unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);
             const float *ff = e->wfoldf + (size_t)l * (6 * D + 2 * H);
-            const int feeds_fold = l + 1 < c->depth; /* the next layer reads x16 / rows */
-            if (l == 0)
-                LANES { /* the only LayerNorm without a residual GEMM in front of it: one pass for bf16(x) and the row pairs */
-                    HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-                    HIP_TRY(e, vithip_rowstats_bf16(lane[j].s, e->x + ROWS(j) * D, (size_t)D, x16 + ROWS(j) * D, (size_t)D,
-                                                    ln_rows + ROWS(j) * 2, lane[j].n * T, D));
-                    HIP_TRY(e, stage_end(e, lane[j].s));
-                }
-            if (last_pruned) { /* the sequence of the LayerNorm-kernel branch below, in folded form: class rows = rows 0, T, 2T, ... */
-                LANES { /* K and V of every token (folded in_proj rows D..3D); Q of the class rows, whose (rstd, mean*rstd) pairs
-                         * are copied out of the per-token array first */
-                    float *cls = cls_rows + (size_t)lane[j].off * 2;
-                    if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_QKV, x16 + ROWS(j) * D, D, f16 + (size_t)D * D, ff + 3 * D + D, ff + D,
-                                        ln_rows + ROWS(j) * 2, qkv16 + ROWS(j) * 3 * D + D, 3 * D, lane[j].n * T, 2 * D, D,
-                                        VITHIP_BF16_EPI_BF16))) return rc;
-                    HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-                    HIP_TRY(e, vithip_gather_rows_f32(lane[j].s, ln_rows + ROWS(j) * 2, (size_t)T * 2, cls, 2, lane[j].n, 2));
-                    HIP_TRY(e, stage_end(e, lane[j].s));
-                    if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_QKV, x16 + ROWS(j) * D, T * D, f16, ff + 3 * D, ff, cls,
-                                        qkv16 + ROWS(j) * 3 * D, T * 3 * D, lane[j].n, D, D, VITHIP_BF16_EPI_BF16))) return rc;
-                }
-                LANES {
-                    HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
-                    HIP_TRY(e, vithip_attention_bf16io_rows(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T,
-                                                            c->num_heads, 1));
-                    HIP_TRY(e, stage_end(e, lane[j].s));
-                }
-                LANES
-                    if ((rc = gemm16_res_stats(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, T * D, lw16[4], lw[5], e->x + ROWS(j) * D,
-                                               x16 + ROWS(j) * D, T * D, PART(j), cls_rows + (size_t)lane[j].off * 2, lane[j].n, D, D))) return rc;
-                LANES
-                    if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_FC1, x16 + ROWS(j) * D, T * D, f16 + 3 * D * D, ff + 6 * D + H, ff + 6 * D,
-                                        cls_rows + (size_t)lane[j].off * 2, h16 + ROWS(j) * H, H, lane[j].n, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
-                LANES
-                    if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
-                                     e->x + ROWS(j) * D, T * D, lane[j].n, D, H, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
-                break;
-            }
-            LANES /* LN1 + in_proj */
-                if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_QKV, x16 + ROWS(j) * D, D, f16, ff + 3 * D, ff, ln_rows + ROWS(j) * 2,
-                                    qkv16 + ROWS(j) * 3 * D, 3 * D, lane[j].n * T, 3 * D, D, VITHIP_BF16_EPI_BF16))) return rc;
-            LANES {
-                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
-                HIP_TRY(e, vithip_attention_bf16io(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T, c->num_heads));
-                HIP_TRY(e, stage_end(e, lane[j].s));
-            }
-            LANES /* out_proj + residual; bf16(x) and row sums for LN2 */
-                if ((rc = gemm16_res_stats(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, D, lw16[4], lw[5], e->x + ROWS(j) * D,
-                                           x16 + ROWS(j) * D, D, PART(j), ln_rows + ROWS(j) * 2, lane[j].n * T, D, D))) return rc;
-            LANES /* LN2 + fc1 + GELU */
-                if ((rc = gemm16_ln(e, lane[j].s, VIT_STAGE_FC1, x16 + ROWS(j) * D, D, f16 + 3 * D * D, ff + 6 * D + H, ff + 6 * D,
-                                    ln_rows + ROWS(j) * 2, h16 + ROWS(j) * H, H, lane[j].n * T, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
-            LANES { /* fc2 + residual; bf16(x) and row sums for the next layer's LN1 */
-                if (feeds_fold)
-                    rc = gemm16_res_stats(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
-                                          x16 + ROWS(j) * D, D, PART(j), ln_rows + ROWS(j) * 2, lane[j].n * T, D, H);
-                else
-                    rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
-                                e->x + ROWS(j) * D, D, lane[j].n * T, D, H, VITHIP_BF16_EPI_F32_RESIDUAL);
-                if (rc) return rc;
-            }
-            continue;
+            RUN(last_pruned ? layer_bf16_folded_pruned(c, lw, lw16, f16, ff, l == 0)
+                            : layer_bf16_folded(c, lw, lw16, f16, ff, l == 0, l + 1 < cfg->depth));
+        } else {
+            RUN(last_pruned ? layer_bf16_pruned(c, lw, lw16) : layer_bf16(c, lw, lw16));
         }
-        LANES {
-            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-            HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)D, y16 + ROWS(j) * D, (size_t)D,
-                                                    lw[0], lw[1], lane[j].n * T, D));
-            HIP_TRY(e, stage_end(e, lane[j].s));
-        }
-        if (prune && l == c->depth - 1) {
-            LANES { /* K and V of every token (in_proj rows D..3D), Q of the class rows only */
-                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_QKV, y16 + ROWS(j) * D, D, lw16[2] + (size_t)D * D, lw[3] + D, NULL,
-                                 qkv16 + ROWS(j) * 3 * D + D, 3 * D, lane[j].n * T, 2 * D, D, VITHIP_BF16_EPI_BF16))) return rc;
-                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_QKV, y16 + ROWS(j) * D, T * D, lw16[2], lw[3], NULL,
-                                 qkv16 + ROWS(j) * 3 * D, T * 3 * D, lane[j].n, D, D, VITHIP_BF16_EPI_BF16))) return rc;
-            }
-            LANES {
-                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
-                HIP_TRY(e, vithip_attention_bf16io_rows(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T,
-                                                        c->num_heads, 1));
-                HIP_TRY(e, stage_end(e, lane[j].s));
-            }
-            LANES
-                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, T * D, lw16[4], lw[5], e->x + ROWS(j) * D,
-                                 e->x + ROWS(j) * D, T * D, lane[j].n, D, D, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
-            LANES { /* LN2 of the class rows -> compact [n][D] at the head of the lane's y region */
-                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-                HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)T * D, y16 + ROWS(j) * D, (size_t)D,
-                                                        lw[6], lw[7], lane[j].n, D));
-                HIP_TRY(e, stage_end(e, lane[j].s));
-            }
-            LANES
-                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC1, y16 + ROWS(j) * D, D, lw16[8], lw[9], NULL,
-                                 h16 + ROWS(j) * H, H, lane[j].n, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
-            LANES
-                if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
-                                 e->x + ROWS(j) * D, T * D, lane[j].n, D, H, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
-            break;
-        }
-        LANES
-            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_QKV, y16 + ROWS(j) * D, D, lw16[2], lw[3], NULL,
-                             qkv16 + ROWS(j) * 3 * D, 3 * D, lane[j].n * T, 3 * D, D, VITHIP_BF16_EPI_BF16))) return rc;
-        LANES {
-            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
-            HIP_TRY(e, vithip_attention_bf16io(lane[j].s, qkv16 + ROWS(j) * 3 * D, y16 + ROWS(j) * D, lane[j].n, T, c->num_heads));
-            HIP_TRY(e, stage_end(e, lane[j].s));
-        }
-        LANES
-            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_OUTPROJ, y16 + ROWS(j) * D, D, lw16[4], lw[5], e->x + ROWS(j) * D,
-                             e->x + ROWS(j) * D, D, lane[j].n * T, D, D, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
-        LANES {
-            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-            HIP_TRY(e, vithip_layernorm_f32_bf16out(lane[j].s, e->x + ROWS(j) * D, (size_t)D, y16 + ROWS(j) * D, (size_t)D,
-                                                    lw[6], lw[7], lane[j].n * T, D));
-            HIP_TRY(e, stage_end(e, lane[j].s));
-        }
-        LANES
-            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC1, y16 + ROWS(j) * D, D, lw16[8], lw[9], NULL,
-                             h16 + ROWS(j) * H, H, lane[j].n * T, H, D, VITHIP_BF16_EPI_BF16_GELU))) return rc;
-        LANES
-            if ((rc = gemm16(e, lane[j].s, VIT_STAGE_FC2, h16 + ROWS(j) * H, H, lw16[10], lw[11], e->x + ROWS(j) * D,
-                             e->x + ROWS(j) * D, D, lane[j].n * T, D, H, VITHIP_BF16_EPI_F32_RESIDUAL))) return rc;
     }
-    for (int l = 0; l < c->depth && !bf16; ++l) {
-        float **lw = w + 4 + VIT_WEIGHTS_PER_LAYER * l;
-        LANES { /* LN1 (ViT_seq.c:281) */
-            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-            HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D,
-                                            lw[0], lw[1], lane[j].n * T, D));
-            HIP_TRY(e, stage_end(e, lane[j].s));
-        }
-        if (prune && l == c->depth - 1) { /* same sequence as the bf16 branch above, fp32 operators */
-            LANES {
-                if ((rc = gemm(e, lane[j].s, VIT_STAGE_QKV, e->y + ROWS(j) * D, D, lw[2] + (size_t)D * D, lw[3] + D, NULL,
-                               e->qkv + ROWS(j) * 3 * D + D, 3 * D, lane[j].n * T, 2 * D, D, VITHIP_EPI_BIAS))) return rc;
-                if ((rc = gemm(e, lane[j].s, VIT_STAGE_QKV, e->y + ROWS(j) * D, T * D, lw[2], lw[3], NULL,
-                               e->qkv + ROWS(j) * 3 * D, T * 3 * D, lane[j].n, D, D, VITHIP_EPI_BIAS))) return rc;
-            }
-            LANES {
-                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
-                HIP_TRY(e, vithip_attention_f32_rows(lane[j].s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, lane[j].n, T,
-                                                     c->num_heads, 1));
-                HIP_TRY(e, stage_end(e, lane[j].s));
-            }
-            LANES
-                if ((rc = gemm(e, lane[j].s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, T * D, lw[4], lw[5], e->x + ROWS(j) * D,
-                               e->x + ROWS(j) * D, T * D, lane[j].n, D, D, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
-            LANES {
-                HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-                HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)T * D, e->y + ROWS(j) * D, (size_t)D,
-                                                lw[6], lw[7], lane[j].n, D));
-                HIP_TRY(e, stage_end(e, lane[j].s));
-            }
-            LANES
-                if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC1, e->y + ROWS(j) * D, D, lw[8], lw[9], NULL,
-                               e->hbuf + ROWS(j) * H, H, lane[j].n, H, D, VITHIP_EPI_BIAS_GELU))) return rc;
-            LANES
-                if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D,
-                               e->x + ROWS(j) * D, T * D, lane[j].n, D, H, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
-            break;
-        }
-        LANES /* QKV in_proj (ViT_seq.c:134-147) */
-            if ((rc = gemm(e, lane[j].s, VIT_STAGE_QKV, e->y + ROWS(j) * D, D, lw[2], lw[3], NULL,
-                           e->qkv + ROWS(j) * 3 * D, 3 * D, lane[j].n * T, 3 * D, D, VITHIP_EPI_BIAS))) return rc;
-        LANES { /* scores, softmax, P.V (ViT_seq.c:156-215) -> y */
-            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_ATTN));
-            HIP_TRY(e, vithip_attention_f32(lane[j].s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, lane[j].n, T, c->num_heads));
-            HIP_TRY(e, stage_end(e, lane[j].s));
-        }
-        LANES /* out_proj + residual (ViT_seq.c:219-227,286-288): x = x + (y.Wo^T + bo) */
-            if ((rc = gemm(e, lane[j].s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, D, lw[4], lw[5], e->x + ROWS(j) * D,
-                           e->x + ROWS(j) * D, D, lane[j].n * T, D, D, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
-        LANES { /* LN2 (ViT_seq.c:291) */
-            HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-            HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)D, e->y + ROWS(j) * D, (size_t)D,
-                                            lw[6], lw[7], lane[j].n * T, D));
-            HIP_TRY(e, stage_end(e, lane[j].s));
-        }
-        LANES /* fc1 + GELU (ViT_seq.c:258-264) */
-            if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC1, e->y + ROWS(j) * D, D, lw[8], lw[9], NULL,
-                           e->hbuf + ROWS(j) * H, H, lane[j].n * T, H, D, VITHIP_EPI_BIAS_GELU))) return rc;
-        LANES /* fc2 + residual (ViT_seq.c:266,297-299): x = x + (h.W2^T + b2) */
-            if ((rc = gemm(e, lane[j].s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D,
-                           e->x + ROWS(j) * D, D, lane[j].n * T, D, H, VITHIP_EPI_BIAS_RESIDUAL))) return rc;
-    }
-
-    /* final LayerNorm on the class-token rows only (ViT_seq.c:429-433 normalises all rows, uses row 0) */
-    float **fw = w + 4 + VIT_WEIGHTS_PER_LAYER * c->depth;
-    LANES {
-        HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_LN));
-        HIP_TRY(e, vithip_layernorm_f32(lane[j].s, e->x + ROWS(j) * D, (size_t)T * D, e->z + (size_t)lane[j].off * D,
-                                        (size_t)D, fw[0], fw[1], lane[j].n, D));
-        HIP_TRY(e, stage_end(e, lane[j].s));
-    }
-    LANES /* classifier head (ViT_seq.c:435) */
-        if ((rc = gemm(e, lane[j].s, VIT_STAGE_HEAD, e->z + (size_t)lane[j].off * D, D, fw[2], fw[3], NULL,
-                       e->logits + (size_t)lane[j].off * NC, NC, lane[j].n, NC, D, VITHIP_EPI_BIAS))) return rc;
-    LANES { /* Softmax (ViT_seq.c:437) + top-1 (Main.c:62-70) */
-        const size_t o = (size_t)lane[j].off;
-        HIP_TRY(e, stage_begin(e, lane[j].s, VIT_STAGE_SOFTMAX));
-        HIP_TRY(e, vithip_softmax_top1_f32(lane[j].s, e->logits + o * NC, NC, d_probs + o * NC, NC,
-                                           d_label ? d_label + o : NULL, d_prob ? d_prob + o : NULL, lane[j].n, NC));
-        HIP_TRY(e, stage_end(e, lane[j].s));
-    }
-#undef LANES
-#undef ROWS
-#undef PART
-    for (int j = 1; j < L; ++j) { /* join */
-        HIP_TRY(e, vithip_event_record(e->ev_join[j - 1], lane[j].s));
+    RUN(stage_head(c, d_probs, d_label, d_prob));
+    for (int j = 1; j < c->L; ++j) { /* join */
+        HIP_TRY(e, vithip_event_record(e->ev_join[j - 1], c->lane[j].s));
         HIP_TRY(e, vithip_stream_wait_event(s, e->ev_join[j - 1]));
     }
     e->last_rows = nb;
     return VIT_OK;
 }
+#undef LANES
+#undef LN_
+#undef ROWS
+#undef PART
+#undef RUN
 
 /* Images per forward_chunk call: the workspace holds max_batch, and no lane may exceed lane_cap (see vit_engine_create). */
 static int chunk_limit(const vit_engine *e) {
