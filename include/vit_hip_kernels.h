@@ -160,6 +160,12 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *args);
  * exactly what the matrix pipe accumulates); bias_f[n] = bias[n] + sum_k beta[k] * W[n][k].  W fp32 [N][K], K % 4 == 0. */
 int vithip_ln_fold_weights(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
                            unsigned short *Wf, float *colsum, float *bias_f, int N, int K);
+/* The same with output features [0, scale_rows) made `scale` times as large (rows of Wf and their bias_f; colsum is taken of the
+ * scaled, rounded rows): the engine folds the factor of the attention scores' exponent, VITHIP_QSCALE, into the Q rows of in_proj,
+ * so that q is still rounded to bf16 once and the attention kernels need no scaling pass (vithip_attention_bf16io_qscaled). */
+#define VITHIP_QSCALE 0.18033688011112042f /* (1/sqrtf(64)) * log2(e): softmax(q.k / 8) = 2^(QSCALE q.k - max) / sum */
+int vithip_ln_fold_weights_scaled(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
+                                  unsigned short *Wf, float *colsum, float *bias_f, int N, int K, int scale_rows, float scale);
 /* x16 = bf16(x) and rows[m] = (rstd, mean * rstd) of fp32 rows x [rows][ldx] (the first LayerNorm of the stack, which has no
  * residual GEMM in front of it). */
 int vithip_rowstats_bf16(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *x16, size_t ldx16,
@@ -185,6 +191,10 @@ int vithip_attention_f32_rows(vithip_stream_t stream, const float *qkv, float *o
                               int q_rows);
 int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images,
                                  int tokens, int heads, int q_rows);
+/* As vithip_attention_bf16io (q_rows = tokens) / _rows, for Q columns that already hold VITHIP_QSCALE * q.  For the streamed
+ * kernel (225..704 tokens) this removes the scale-and-subtract of every score: the score accumulators start at -max. */
+int vithip_attention_bf16io_qscaled(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images,
+                                    int tokens, int heads, int q_rows);
 /* Patch embedding on the bf16 matrix pipe (same result layout as vithip_patch_embed_f32: x[n][tokens][D] fp32 with
  * class token and pos_emb applied; ViT_seq.c:25-101): the images are cut into bf16 patch rows
  * (patches16: workspace of n * (img/patch)^2 * chans*patch^2 bf16), multiplied with the bf16 conv weight

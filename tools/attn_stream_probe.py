@@ -9,14 +9,21 @@ from tools.gemm_probe import timed
 n, T, heads = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 577, 16
 D = heads * 64
 rng = np.random.default_rng(0)
-q = B.to_bf16_bits(rng.uniform(-1.5, 1.5, (n * T, 3 * D)).astype(np.float32))
-dq = B.DeviceArray.from_numpy(q)
+vals = rng.uniform(-1.5, 1.5, (n * T, 3 * D)).astype(np.float32)
+dq = B.DeviceArray.from_numpy(B.to_bf16_bits(vals))
+vals[:, :D] *= np.float32(B.QSCALE)          # what the engine's folded in_proj writes into the Q columns
+dqs = B.DeviceArray.from_numpy(B.to_bf16_bits(vals))
+del vals
 do = B.DeviceArray((n * T, D), np.uint16)
 L = B.lib()
 L.vithip_attention_bf16io.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
-ms = [timed(lambda: B.hip_check(L.vithip_attention_bf16io(None, dq.ptr, do.ptr, n, T, heads)), reps=5, warm=2) for _ in range(3)]
 flop = 2.0 * n * 2 * heads * T * T * 64
-print(json.dumps({"attention_ms": [round(m, 4) for m in ms], "tflops": round(flop / (min(ms) * 1e-3) / 1e12, 1)}))
+L.vithip_attention_bf16io_qscaled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+for rnd in range(2):   # interleaved A/B in one process: plain q, then the q-scaled entry (same bits: timing only)
+    ms = [timed(lambda: B.hip_check(L.vithip_attention_bf16io(None, dq.ptr, do.ptr, n, T, heads)), reps=5, warm=2) for _ in range(3)]
+    print(json.dumps({"attention_ms": [round(m, 4) for m in ms], "tflops": round(flop / (min(ms) * 1e-3) / 1e12, 1)}))
+    ms = [timed(lambda: B.hip_check(L.vithip_attention_bf16io_qscaled(None, dqs.ptr, do.ptr, n, T, heads, T)), reps=5, warm=2) for _ in range(3)]
+    print(json.dumps({"qscaled_attention_ms": [round(m, 4) for m in ms], "tflops": round(flop / (min(ms) * 1e-3) / 1e12, 1)}))
 if hasattr(L, "vithip_attention_set_debug_buffer"):
     dbg = B.DeviceArray((256 * 8, 16), np.uint64)
     L.vithip_attention_set_debug_buffer.argtypes = [C.c_void_p]

@@ -372,13 +372,23 @@ def layernorm_bf16out(x, gamma, beta) -> np.ndarray:
     return dy.numpy()
 
 
-def attention_bf16io(qkv_bits, n_images: int, tokens: int, heads: int, f32math: bool = False) -> np.ndarray:
-    """vithip_attention_bf16io (bf16 MFMA) or vithip_attention_bf16io_f32math (fp32 arithmetic) -> bf16 bits."""
+QSCALE = 0.18033688011112042  # VITHIP_QSCALE: (1/sqrt(64)) * log2(e)
+
+
+def attention_bf16io(qkv_bits, n_images: int, tokens: int, heads: int, f32math: bool = False, q_scaled: bool = False,
+                     q_rows: Optional[int] = None) -> np.ndarray:
+    """vithip_attention_bf16io (bf16 MFMA), vithip_attention_bf16io_f32math (fp32 arithmetic) or, q_scaled,
+    vithip_attention_bf16io_qscaled (the Q columns hold QSCALE * q) -> bf16 bits."""
     D = heads * 64
-    fn = getattr(lib(), "vithip_attention_bf16io_f32math" if f32math else "vithip_attention_bf16io")
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     dq = DeviceArray.from_numpy(np.ascontiguousarray(qkv_bits, np.uint16))
     do = DeviceArray((n_images * tokens, D), np.uint16)
+    if q_scaled:
+        fn = lib().vithip_attention_bf16io_qscaled
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        hip_check(fn(None, dq.ptr, do.ptr, n_images, tokens, heads, q_rows or tokens), "vithip_attention_bf16io_qscaled")
+        return do.numpy()
+    fn = getattr(lib(), "vithip_attention_bf16io_f32math" if f32math else "vithip_attention_bf16io")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     hip_check(fn(None, dq.ptr, do.ptr, n_images, tokens, heads), "vithip_attention_bf16io")
     return do.numpy()
 

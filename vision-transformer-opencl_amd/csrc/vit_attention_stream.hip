@@ -45,6 +45,24 @@ constexpr int SBUF = 2 * SKEYS * SHD;    // bf16 elements of one ring slot: K[12
 constexpr int MAXB = 3;                  // query blocks per wave: tokens <= 8 * 3 * 32 = 768
 constexpr int SUB = 2;                   // key tiles whose scores are in registers at a time
 constexpr float kScaleS = 0.125f * 1.4426950408889634f;
+#ifdef VIT_PROBES
+unsigned long long *g_stream_dbg = nullptr;
+#endif
+
+// fp32 adds stay single instructions in this file (Makefile: -fno-slp-vectorize): beside MFMAs the packed forms (v_pk_add_f32 /
+// v_pk_fma_f32, which hipcc makes of adjacent scalar operations under plain -O3) cost more than the two scalar instructions
+// they replace (CDNA4 guide, cycle constants).  Not inline asm: hipcc inserts no wait state between a v_exp_f32 and an asm
+// statement that reads its result (the transcendental-use hazard), and the sums came out wrong.
+// max over the two half-waves' values (lane l and lane l ^ 32) without an LDS round trip (ds_bpermute): v_permlane32_swap
+__device__ __forceinline__ float max_halves(float x) {
+    // the instruction swaps the upper half of its first register with the lower half of its second: afterwards either half
+    // holds {its own value, its partner's} in (a, b) or (b, a).  Inline asm: given the builtin with two copies of one value
+    // hipcc (ROCm 7.2) drops the max of the two results; the s_nop covers the VALU-write -> permlane-read wait states it would
+    // have inserted itself.
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
 
 // A fragment of O^T = V^T . P^T for d-tile dt and the 16 keys from key16 (see attention_bf16_kernel): lane 4q+p of a
 // 16-lane group addresses key row q, d columns 4p..4p+3 of a 4 x 16 block and receives column i.  EXEC all ones.
@@ -59,6 +77,12 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const bf16_t *Vs, int key16, int dt,
     return __builtin_bit_cast(bf16x8, both);
 }
 
+// QS: the Q columns of qkv hold c * q, c = 0.125 * log2(e) (the engine folds c into the in_proj weights, so q is rounded to bf16
+// once either way).  The scores then come out of the matrix pipe in the exponent's units, and the accumulator of a score tile is
+// INITIALISED with -m (the row's reference maximum): s - m costs no instruction, and the scale-and-subtract FMA of every score --
+// a fifth of the softmax's VALU time, which is what bounds this kernel -- is gone.  The reference can move between that
+// initialisation and the softmax (the units are software-pipelined): the rows it moved for are then corrected by one add.
+template <bool QS>
 __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                                            int tokens, int heads, int n_items
 #ifdef VIT_PROBES
@@ -200,6 +224,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
         const bool two = SUB * 32 < valid;                      // wave-uniform: the chunk has a second sub-chunk
 
         f32x16 st[2][SUB];  // two score buffers
+        [[maybe_unused]] float m_init[2] = {0.0f, 0.0f};  // QS: the reference the buffer's accumulators were initialised with (finite)
         // scores of sub-chunk k0 of block b -> buffer `buf`.  A sub-chunk is always computed whole: keys past `valid` (a
         // chunk of 3 tiles, the end of the sequence) hold older, finite data in LDS and are masked to -inf below.
         auto scores = [&](int buf, int b, int k0) __attribute__((always_inline)) {
@@ -207,10 +232,16 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             bf16x8 qf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qrow + (((2 * ks + h) ^ sw) & 7) * 8);
+            float init = 0.0f;
+            if constexpr (QS) {
+                const float mr = m_run[b];
+                m_init[buf] = mr == -INFINITY ? 0.0f : mr;  // a block's first unit has no reference yet
+                init = -m_init[buf];
+            }
 #pragma unroll
             for (int u = 0; u < SUB; ++u)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) st[buf][u][v] = 0.0f;
+                for (int v = 0; v < 16; ++v) st[buf][u][v] = init;
             // K fragments are read one k-step AHEAD of the MFMAs that use them (two register sets): left to itself hipcc issues
             // read - wait - MFMA for every instruction, i.e. every MFMA pays an LDS round trip
             bf16x8 kf[2][SUB];
@@ -248,29 +279,60 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 #pragma unroll
                 for (int v = 0; v < 16; v += 2) mx2 = __builtin_elementwise_max(mx2, f32x2{st[buf][u][v], st[buf][u][v + 1]});
             float cmax = fmaxf(mx2[0], mx2[1]);
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            cmax = QS ? max_halves(cmax) : fmaxf(cmax, __shfl_xor(cmax, 32));
             // The running maximum is a REFERENCE, not a bound: it moves only when a row's scores outgrow it by more than
             // kDefer in the exponent (T13 of the CDNA4 guide).  P then reaches 2^kDefer instead of 1 -- the same relative
             // precision in bf16 and in the fp32 sums -- and the O-wide rescale below, which used to run in almost every
             // sub-chunk (some row of 32 nearly always finds a slightly larger score), runs a few times per head.
             constexpr float kDefer = 8.0f;
             const float m_old = m_run[b];
-            const float m_new = (cmax - m_old) * kScaleS > kDefer ? cmax : m_old;  // first sub-chunk: m_old = -inf -> cmax (finite)
-            m_run[b] = m_new;
-            const f32x2 sc2 = {kScaleS, kScaleS}, mxs2 = {-m_new * kScaleS, -m_new * kScaleS};
             f32x2 sum2 = {0.0f, 0.0f};
+            float m_new;
+            if constexpr (QS) {
+                // st = s - m_init (already in the exponent's units).  Common case: the reference stays (m_new == m_old == m_init)
+                // and the exponentials are taken of the accumulators as they stand.
+                const float smax = cmax + m_init[buf];
+                m_new = smax - m_old > kDefer ? smax : m_old;  // first unit: m_old = -inf -> smax (finite)
+                m_run[b] = m_new;
+                const float delta = m_init[buf] - m_new;       // 0 unless the reference moved since the initialisation
+                if (__any(delta != 0.0f)) {                    // wave-uniform
+                    const f32x2 d2 = {delta, delta};
 #pragma unroll
-            for (int u = 0; u < SUB; ++u)
+                    for (int u = 0; u < SUB; ++u)
 #pragma unroll
-                for (int v = 0; v < 16; v += 2) {
-                    const f32x2 t = __builtin_elementwise_fma(f32x2{st[buf][u][v], st[buf][u][v + 1]}, sc2, mxs2);
-                    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};  // exp2(-inf) = 0: masked keys
-                    st[buf][u][v] = e[0];
-                    st[buf][u][v + 1] = e[1];
-                    sum2 += e;
+                        for (int v = 0; v < 16; v += 2) {
+                            const f32x2 t = f32x2{st[buf][u][v], st[buf][u][v + 1]} + d2;
+                            st[buf][u][v] = t[0];
+                            st[buf][u][v + 1] = t[1];
+                        }
                 }
+                float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const float e = __builtin_amdgcn_exp2f(st[buf][u][v]);  // exp2(-inf) = 0: masked keys
+                        st[buf][u][v] = e;
+                        s4[v & 3] += e;
+                    }
+                sum2 = f32x2{s4[0] + s4[1], s4[2] + s4[3]};
+            } else {
+                m_new = (cmax - m_old) * kScaleS > kDefer ? cmax : m_old;  // first sub-chunk: m_old = -inf -> cmax (finite)
+                m_run[b] = m_new;
+                const f32x2 sc2 = {kScaleS, kScaleS}, mxs2 = {-m_new * kScaleS, -m_new * kScaleS};
+#pragma unroll
+                for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                    for (int v = 0; v < 16; v += 2) {
+                        const f32x2 t = __builtin_elementwise_fma(f32x2{st[buf][u][v], st[buf][u][v + 1]}, sc2, mxs2);
+                        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};  // exp2(-inf) = 0: masked keys
+                        st[buf][u][v] = e[0];
+                        st[buf][u][v + 1] = e[1];
+                        sum2 += e;
+                    }
+            }
             if (__any(m_new != m_old)) {  // wave-uniform: most sub-chunks leave every row's maximum where it was
-                const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * kScaleS);  // first one: exp2(-inf) = 0
+                const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * (QS ? 1.0f : kScaleS));  // first one: exp2(-inf) = 0
                 l_run[b] *= alpha;
                 const f32x2 a2 = {alpha, alpha};
 #pragma unroll
@@ -378,6 +440,8 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             step(slot, item, ch, ni, nc);
             ST_STAMP();
             if (ch == nch - 1) {
+                // (Tried: normalising and storing a block, and refilling its Q slot, right after its last unit inside the last
+                // step, so that the stores run beside the other waves' work instead of as one burst: no gain, 2.35 vs 2.35 ms.)
                 finish_item(item);
                 if (next_item < n_items) dma_q(next_item);  // this wave is done with its Q blocks: refill them for the next head
             }
@@ -402,33 +466,37 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 #undef ST_STAMP
 }
 
+// 224 < tokens <= 704 (the head's Q blocks share the LDS with the K/V ring).  q_scaled: the Q columns hold 0.125 * log2(e) * q.
+// Returns a hipError_t value.
+template <bool QS>
+static int launch_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int tokens, int heads, int items, int grid,
+                         size_t lds_bytes, int dev) {
+    static vitdev::PerDeviceOnce attr_set;  // the attribute belongs to this device's copy of the kernel
+    if (!attr_set.is_done(dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bf16_stream_kernel<QS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return static_cast<int>(e);
+        attr_set.set(dev);
+    }
 #ifdef VIT_PROBES
-unsigned long long *g_stream_dbg = nullptr;
+    hipLaunchKernelGGL(attention_bf16_stream_kernel<QS>, dim3(grid), dim3(ST_THREADS), lds_bytes, s, qkv, out, tokens, heads, items, g_stream_dbg);
+#else
+    hipLaunchKernelGGL(attention_bf16_stream_kernel<QS>, dim3(grid), dim3(ST_THREADS), lds_bytes, s, qkv, out, tokens, heads, items);
 #endif
+    return static_cast<int>(hipGetLastError());
+}
 
-// 224 < tokens <= 704 (the head's Q blocks share the LDS with the K/V ring).  Returns a hipError_t value.
-int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads) {
+int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads, bool q_scaled) {
     int dev = 0;
     const int cus = vitdev::current_cus(&dev);
     if (cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     const int nblk = (tokens + 31) / 32;
     const size_t lds_bytes = (size_t)(2 * SBUF + nblk * 32 * SHD) * sizeof(bf16_t);  // ring + the head's Q blocks
     if (tokens > ST_WAVES * MAXB * 32 || lds_bytes > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
-    static vitdev::PerDeviceOnce attr_set;  // the attribute belongs to this device's copy of the kernel
-    if (!attr_set.is_done(dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bf16_stream_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return static_cast<int>(e);
-        attr_set.set(dev);
-    }
     const int items = n_images * heads;
     const int grid = items < cus ? items : cus;
-#ifdef VIT_PROBES
-    hipLaunchKernelGGL(attention_bf16_stream_kernel, dim3(grid), dim3(ST_THREADS), lds_bytes, s, qkv, out, tokens, heads, items, g_stream_dbg);
-#else
-    hipLaunchKernelGGL(attention_bf16_stream_kernel, dim3(grid), dim3(ST_THREADS), lds_bytes, s, qkv, out, tokens, heads, items);
-#endif
-    return static_cast<int>(hipGetLastError());
+    return q_scaled ? launch_stream<true>(s, qkv, out, tokens, heads, items, grid, lds_bytes, dev)
+                    : launch_stream<false>(s, qkv, out, tokens, heads, items, grid, lds_bytes, dev);
 }
 
 }  // namespace vitattn

@@ -33,10 +33,11 @@ __device__ __forceinline__ f32x2 finish(float s, float ss, int dim) {
 __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float *__restrict__ W, const float *__restrict__ bias,
                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
                                                               unsigned short *__restrict__ Wf, float *__restrict__ colsum,
-                                                              float *__restrict__ bias_f, int N, int K) {
+                                                              float *__restrict__ bias_f, int N, int K, int scale_rows, float scale) {
     const int lane = threadIdx.x & 63;
     const int n = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (n >= N) return;  // wave-uniform
+    const float sc = n < scale_rows ? scale : 1.0f;  // output features [0, scale_rows) are produced `scale` times as large
     const float *src = W + (size_t)n * K;
     unsigned short *dst = Wf + (size_t)n * K;
     float cs = 0.f, bs = 0.f;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float *__res
         bf16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            o[j] = (__bf16)(g[j] * w[j]);
+            o[j] = (__bf16)(sc * (g[j] * w[j]));
             cs += (float)o[j];
             bs += b[j] * w[j];
         }
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float *__res
     bs = wave_sum(bs);
     if (lane == 0) {
         colsum[n] = cs;
-        bias_f[n] = bias[n] + bs;
+        bias_f[n] = sc * (bias[n] + bs);
     }
 }
 
@@ -120,15 +121,20 @@ extern "C" {
 
 int vithip_ln_strips(int N) { return N > 0 ? 4 * ((N + 255) / 256) : 0; }
 
-int vithip_ln_fold_weights(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
-                           unsigned short *Wf, float *colsum, float *bias_f, int N, int K) {
-    if (!W || !bias || !gamma || !beta || !Wf || !colsum || !bias_f || N <= 0 || K <= 0 || K % 4)
+int vithip_ln_fold_weights_scaled(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
+                                  unsigned short *Wf, float *colsum, float *bias_f, int N, int K, int scale_rows, float scale) {
+    if (!W || !bias || !gamma || !beta || !Wf || !colsum || !bias_f || N <= 0 || K <= 0 || K % 4 || scale_rows < 0 || scale_rows > N)
         return static_cast<int>(hipErrorInvalidValue);
     if (!aligned16(W) || !aligned16(gamma) || !aligned16(beta) || (reinterpret_cast<size_t>(Wf) & 7))
         return static_cast<int>(hipErrorInvalidValue);
     hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), W, bias, gamma,
-                       beta, Wf, colsum, bias_f, N, K);
+                       beta, Wf, colsum, bias_f, N, K, scale_rows, scale);
     return static_cast<int>(hipGetLastError());
+}
+
+int vithip_ln_fold_weights(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
+                           unsigned short *Wf, float *colsum, float *bias_f, int N, int K) {
+    return vithip_ln_fold_weights_scaled(stream, W, bias, gamma, beta, Wf, colsum, bias_f, N, K, 0, 1.0f);
 }
 
 int vithip_rowstats_bf16(vithip_stream_t stream, const float *x, size_t ldx, unsigned short *x16, size_t ldx16, float *rows_out,

@@ -355,7 +355,8 @@ static int fold_ln_weights(vit_engine *e) {
         float **lw = e->w + 4 + VIT_WEIGHTS_PER_LAYER * l;
         unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);
         float *ff = e->wfoldf + (size_t)l * (6 * D + 2 * H);
-        HIP_TRY(e, vithip_ln_fold_weights(e->stream, lw[2], lw[3], lw[0], lw[1], f16, ff, ff + 3 * D, (int)(3 * D), (int)D));
+        /* in_proj: the Q rows also carry the factor of the scores' exponent (the attention kernels are told: _qscaled) */
+        HIP_TRY(e, vithip_ln_fold_weights_scaled(e->stream, lw[2], lw[3], lw[0], lw[1], f16, ff, ff + 3 * D, (int)(3 * D), (int)D, (int)D, VITHIP_QSCALE));
         HIP_TRY(e, vithip_ln_fold_weights(e->stream, lw[8], lw[9], lw[6], lw[7], f16 + 3 * D * D, ff + 6 * D, ff + 6 * D + H, (int)H, (int)D));
     }
     return VIT_OK;
@@ -743,7 +744,7 @@ static int layer_bf16_folded(chunk_ctx *c, float **lw, unsigned short **lw16, co
         RUN(gemm16_ln(e, LN_.s, VIT_STAGE_QKV, c->x16 + ROWS(j) * D, D, f16, ff + 3 * D, ff, c->ln_rows + ROWS(j) * 2, c->qkv16 + ROWS(j) * 3 * D, 3 * D, LN_.n * T, 3 * D, D, VITHIP_BF16_EPI_BF16));
     LANES {
         HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
-        HIP_TRY(e, vithip_attention_bf16io(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads));
+        HIP_TRY(e, vithip_attention_bf16io_qscaled(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, T));
         HIP_TRY(e, stage_end(e, LN_.s));
     }
     LANES /* out_proj + residual; bf16(x) and row sums for LN2 */
@@ -780,7 +781,7 @@ static int layer_bf16_folded_pruned(chunk_ctx *c, float **lw, unsigned short **l
     }
     LANES {
         HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
-        HIP_TRY(e, vithip_attention_bf16io_rows(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, 1));
+        HIP_TRY(e, vithip_attention_bf16io_qscaled(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, 1));
         HIP_TRY(e, stage_end(e, LN_.s));
     }
     LANES
