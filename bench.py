@@ -159,6 +159,9 @@ def main() -> None:
                     help="BASELINE.json configs[i] preset: 1 = fp32 batch 256 (the metric, the default), 2 = bf16 batch 2048, "
                          "3 = bf16 2048 per GPU (global 16384 at --gpus 8), 4 = ViT-L/16-384 bf16 batch 1024")
     ap.add_argument("--no-c-surface", action="store_true", help="skip the host-pointer (ViT_opencl-shaped) timing after the timed region")
+    ap.add_argument("--lane-split", type=int, default=-1, choices=(-1, 0, 1),
+                    help="bf16 with lanes > 1: 1 = every lane's persistent launches take 1/lanes of the CUs (lanes side by side), "
+                         "0 = whole-chip launches that alternate; -1 = the default for the dtype")
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes from this process even for --gpus 1 (N > 1 always does when not "
                          "already launched): exercises the launcher and the RCCL gather at world size 1")
@@ -208,7 +211,8 @@ def main() -> None:
     # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
     # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
     eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1 and not args.graph and not args.no_stage_brackets), lanes=args.lanes,
-                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph, gemm_tile=args.gemm_tile, ln_fold=args.ln_fold)
+                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph, gemm_tile=args.gemm_tile, ln_fold=args.ln_fold,
+                         lane_split=max(args.lane_split, 0))
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the

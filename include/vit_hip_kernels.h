@@ -147,6 +147,10 @@ typedef struct {
     const float *ln_rows, *ln_colsum;
     unsigned short *x16; int ldx16;
     float *row_partials;
+    /* cap on the persistent workgroups of the launch (0 = one per CU): an engine that runs L lanes gives every lane's launches
+     * 1/L of the CUs, so that one lane's HBM-bound phases (residual epilogues, attention) run beside another lane's matrix phases
+     * instead of each launch waiting for the whole chip */
+    int max_workgroups;
 } vithip_gemm_bf16_args;
 /* C = epilogue(A . W^T + bias) on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16 in the ping-pong kernel,
  * v_mfma_f32_32x32x16_bf16 in the two-stage one), fp32 accumulate.  BF16_GELU rounds gelu(acc + bias) to bf16 (a
@@ -194,7 +198,7 @@ int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsigned short *q
 /* As vithip_attention_bf16io (q_rows = tokens) / _rows, for Q columns that already hold VITHIP_QSCALE * q.  For the streamed
  * kernel (225..704 tokens) this removes the scale-and-subtract of every score: the score accumulators start at -max. */
 int vithip_attention_bf16io_qscaled(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images,
-                                    int tokens, int heads, int q_rows);
+                                    int tokens, int heads, int q_rows, int max_workgroups /* 0 = as many as the device holds */);
 /* Patch embedding on the bf16 matrix pipe (same result layout as vithip_patch_embed_f32: x[n][tokens][D] fp32 with
  * class token and pos_emb applied; ViT_seq.c:25-101): the images are cut into bf16 patch rows
  * (patches16: workspace of n * (img/patch)^2 * chans*patch^2 bf16), multiplied with the bf16 conv weight

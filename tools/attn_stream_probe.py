@@ -18,11 +18,11 @@ do = B.DeviceArray((n * T, D), np.uint16)
 L = B.lib()
 L.vithip_attention_bf16io.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
 flop = 2.0 * n * 2 * heads * T * T * 64
-L.vithip_attention_bf16io_qscaled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+L.vithip_attention_bf16io_qscaled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
 for rnd in range(2):   # interleaved A/B in one process: plain q, then the q-scaled entry (same bits: timing only)
     ms = [timed(lambda: B.hip_check(L.vithip_attention_bf16io(None, dq.ptr, do.ptr, n, T, heads)), reps=5, warm=2) for _ in range(3)]
     print(json.dumps({"attention_ms": [round(m, 4) for m in ms], "tflops": round(flop / (min(ms) * 1e-3) / 1e12, 1)}))
-    ms = [timed(lambda: B.hip_check(L.vithip_attention_bf16io_qscaled(None, dqs.ptr, do.ptr, n, T, heads, T)), reps=5, warm=2) for _ in range(3)]
+    ms = [timed(lambda: B.hip_check(L.vithip_attention_bf16io_qscaled(None, dqs.ptr, do.ptr, n, T, heads, T, 0)), reps=5, warm=2) for _ in range(3)]
     print(json.dumps({"qscaled_attention_ms": [round(m, 4) for m in ms], "tflops": round(flop / (min(ms) * 1e-3) / 1e12, 1)}))
 if hasattr(L, "vithip_attention_set_debug_buffer"):
     dbg = B.DeviceArray((256 * 8, 16), np.uint64)

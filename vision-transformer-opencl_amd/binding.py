@@ -49,7 +49,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
                 ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int), ("ln_fold", C.c_int),
-                ("gemm_handover_test", C.c_int)]
+                ("gemm_handover_test", C.c_int), ("lane_split", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -264,7 +264,7 @@ class CGemmBf16Args(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
                 ("variant", C.c_int), ("two_barriers", C.c_int), ("stagger", C.c_int),
                 ("ln_rows", C.c_void_p), ("ln_colsum", C.c_void_p), ("x16", C.c_void_p), ("ldx16", C.c_int),
-                ("row_partials", C.c_void_p)]
+                ("row_partials", C.c_void_p), ("max_workgroups", C.c_int)]
 
 
 BF16_EPI_BF16, BF16_EPI_BF16_GELU, BF16_EPI_F32_RESIDUAL = 0, 1, 2
@@ -384,8 +384,8 @@ def attention_bf16io(qkv_bits, n_images: int, tokens: int, heads: int, f32math: 
     do = DeviceArray((n_images * tokens, D), np.uint16)
     if q_scaled:
         fn = lib().vithip_attention_bf16io_qscaled
-        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
-        hip_check(fn(None, dq.ptr, do.ptr, n_images, tokens, heads, q_rows or tokens), "vithip_attention_bf16io_qscaled")
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        hip_check(fn(None, dq.ptr, do.ptr, n_images, tokens, heads, q_rows or tokens, 0), "vithip_attention_bf16io_qscaled")
         return do.numpy()
     fn = getattr(lib(), "vithip_attention_bf16io_f32math" if f32math else "vithip_attention_bf16io")
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -487,12 +487,12 @@ class Engine:
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
                  lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False,
-                 gemm_tile: int = 0, ln_fold: int = 0, gemm_handover_test: int = 0):
+                 gemm_tile: int = 0, ln_fold: int = 0, gemm_handover_test: int = 0, lane_split: int = 0):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
         opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
-                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold, gemm_handover_test)
+                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold, gemm_handover_test, lane_split)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

@@ -373,8 +373,10 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
     }
 #endif
     if constexpr (AMODE == A_PATCHES) {
-        // 0.7 % of the FLOPs: one moderate-register instantiation is enough (the gather indices and
-        // the token-row remap of the fused epilogue cost ~40 VGPRs on top of the dense kernel)
+        // 0.7 % of the FLOPs (the gather indices and the token-row remap of the fused epilogue cost ~40 VGPRs on top of the dense
+        // kernel).  tile 1 / 2: 128x128 / 256x128 (probe override); default 128x64
+        if (tile == 1) return launch_tile<128, 128, 64, 64, A_PATCHES>(stream, p, epilogue);
+        if (tile == 2) return launch_tile<256, 128, 128, 64, A_PATCHES>(stream, p, epilogue);
         return launch_tile<128, 64, 64, 32, A_PATCHES>(stream, p, epilogue);
     }
     switch (tile) {

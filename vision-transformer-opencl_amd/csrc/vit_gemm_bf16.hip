@@ -473,7 +473,9 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
         return vitgemm::launch_gemm_bf16_pp(s, p, 300 + a->epilogue, g_max_wgs ? g_max_wgs : g_cus);
     }
 #endif
-    if (variant != 1 && pp_ok) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);
+    if (a->max_workgroups < 0) return static_cast<int>(hipErrorInvalidValue);
+    if (variant != 1 && pp_ok)
+        return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, a->max_workgroups > 0 && a->max_workgroups < g_cus ? a->max_workgroups : g_cus);
     switch (a->epilogue) {
 #ifdef VIT_PROBES
         case 101: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 1>), grid, block, 0, s, p); break;

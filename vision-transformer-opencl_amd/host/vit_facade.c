@@ -119,7 +119,8 @@ static void *dev_thread(void *arg) {
     return NULL;
 }
 
-/* run jobs[first..n) on their own threads, jobs[first] on the calling thread when `inline_first` */
+/* run jobs[0..n): jobs[0] on the calling thread, every other job on a thread of its own (one host thread per device);
+ * exits through DIE(what ...) when a job failed */
 static void run_jobs(dev_job *jobs, int n, const char *what) {
     pthread_t th[VIT_MAX_DEVICES];
     int started[VIT_MAX_DEVICES] = {0};
