@@ -15,7 +15,7 @@ w = B.DeviceArray.from_numpy(rng.uniform(-.05, .05, (768, 768)).astype(np.float3
 b = B.DeviceArray((768,)); cls = B.DeviceArray((768,)); pos = B.DeviceArray((197, 768)); x = B.DeviceArray((n * 197, 768))
 flop = 2.0 * n * 196 * 768 * 768
 for rnd in range(2):
-    for tile in (0, 1, 2):
+    for tile in (0, 10, 3):   # 0 = pipelined 128x64 (the default), 10 = pipelined 128x128, 3 = classic 128x64 (the round-2 kernel)
         if hasattr(L, "vithip_gemm_set_tile"):
             L.vithip_gemm_set_tile(tile)
         elif tile:

@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
             const int im = m / p.patches, pp = m - im * p.patches;
             const int oh = pp / p.grid, ow = pp - oh * p.grid;
             a_src[i] = p.A + ((size_t)im * p.chans * p.img + (size_t)oh * p.patch) * p.img + ow * p.patch;
-            a_boff[i] = 0;
+            // pipelined loop (launcher: patch*patch % BK == 0 and BK % patch == 0 or patch % BK == 0): a thread's four k stay in one
+            // pixel row and its (kh, kw) inside the K step never change, so the gather is (per-thread byte offset) + (scalar offset
+            // of the K step) like a dense operand -- buffer loads, no vector address arithmetic in the loop
+            a_boff[i] = (int)(((((size_t)im * p.chans * p.img + (size_t)oh * p.patch + ld_kc / p.patch) * p.img) + ow * p.patch + ld_kc % p.patch) * 4);
         }
     }
 #pragma unroll
@@ -192,11 +195,11 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
             for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * LDS_LD);
         };
         // one staging slot: write the float4 loaded a K step ago, then reload it for two steps ahead
-        auto restage_slot = [&](int q, int buf, int k0) {
+        auto restage_slot = [&](int q, int buf, int k0, int ka) {
             if (q < A_CHUNKS) {
                 float *As = As0 + buf * BM * LDS_LD;
                 *reinterpret_cast<f32x4 *>(As + (ld_row + q * ROWS_PER_PASS) * LDS_LD + ld_kc) = a_stage[q];
-                a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_boff[q], k0 * 4, 0));
+                a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_boff[q], ka, 0));
             } else {
                 const int qb = q - A_CHUNKS;
                 float *Bs = Bs0 + buf * BN * LDS_LD;
@@ -204,10 +207,23 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
                 b_stage[qb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_boff[qb], k0 * 4, 0));
             }
         };
-        static_assert(AMODE == A_DENSE, "pipelined loop: dense A only");
-        load_global(0);
+        // byte offset of K step k0 inside a row's operand: dense k0 * 4; patches: channel k0 / P^2, pixel row (k0 % P^2) / P
+        auto a_koff = [&](int k0) {
+            if constexpr (AMODE == A_DENSE) return k0 * 4;
+            const int pp2 = p.patch * p.patch;
+            const int ic = k0 / pp2, kh = (k0 - ic * pp2) / p.patch;  // wave-uniform: scalar divisions, once per K step
+            return ((ic * p.img + kh) * p.img) * 4;
+        };
+        auto load_global_pipe = [&](int k0) {
+            const int ka = a_koff(k0);
+#pragma unroll
+            for (int i = 0; i < A_CHUNKS; ++i) a_stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_boff[i], ka, 0));
+#pragma unroll
+            for (int i = 0; i < B_CHUNKS; ++i) b_stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_boff[i], k0 * 4, 0));
+        };
+        load_global_pipe(0);
         store_lds(0);
-        load_global(nk > 1 ? BK : 0);
+        load_global_pipe(nk > 1 ? BK : 0);
         __syncthreads();
         read_frags(0, 0, 0);
         if constexpr (DBG == 5) st_clk1 = __builtin_amdgcn_s_memtime();
@@ -216,6 +232,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
             // Branch-free body: past the end the staging just re-reads the last K step and writes a
             // buffer nobody reads again.
             const int k_ahead = (kt + 2 < nk ? kt + 2 : nk - 1) * BK;
+            const int ka_ahead = a_koff(k_ahead);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if (c + 1 < NC) read_frags(cur, c + 1, (c + 1) & 1);
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
                         if (slot_after > slot_before) {
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int q = slot_before; q < slot_after; ++q) restage_slot(q, cur ^ 1, k_ahead);
+                            for (int q = slot_before; q < slot_after; ++q) restage_slot(q, cur ^ 1, k_ahead, ka_ahead);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -322,7 +339,7 @@ int launch_tile(hipStream_t stream, GemmParams &p, int epilogue) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const dim3 grid(p.tiles_m * p.tiles_n), block(256);
     if constexpr (AMODE == A_PATCHES) {
-        hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS, A_PATCHES, 0, BK>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS, A_PATCHES, 0, BK, PIPE>), grid, block, 0, stream, p);
     } else {
         switch (epilogue) {
             case VITHIP_EPI_BIAS:
@@ -375,9 +392,18 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
     if constexpr (AMODE == A_PATCHES) {
         // 0.7 % of the FLOPs (the gather indices and the token-row remap of the fused epilogue cost ~40 VGPRs on top of the dense
         // kernel).  tile 1 / 2: 128x128 / 256x128 (probe override); default 128x64
+        // pipelined loop when a K step of 32 is a whole number of pixel rows or a part of one (patch 8, 16, 32, ...) and the images
+        // are addressable by 32-bit byte offsets; the classic loop (tile 3) otherwise
+        const bool pipe_ok = (32 % p.patch == 0 || p.patch % 32 == 0) && (p.patch * p.patch) % 32 == 0 &&
+                             (size_t)(p.M / p.patches + 1) * p.chans * p.img * p.img * 4 < 0x7fffffffull;
         if (tile == 1) return launch_tile<128, 128, 64, 64, A_PATCHES>(stream, p, epilogue);
         if (tile == 2) return launch_tile<256, 128, 128, 64, A_PATCHES>(stream, p, epilogue);
-        return launch_tile<128, 64, 64, 32, A_PATCHES>(stream, p, epilogue);
+        if (tile == 3 || !pipe_ok) return launch_tile<128, 64, 64, 32, A_PATCHES>(stream, p, epilogue);
+        // measured at batch 256 (tools/embed_f32_time.py, two interleaved rounds): classic 128x64 0.556 ms, pipelined 128x128
+        // 0.504-0.556, pipelined 128x64 0.499-0.531 = 118 TFLOP/s (0.75 of the fp32 matrix peak): every 64-wide N tile re-reads its
+        // pixels through the L2s, 12 x 154 MB per launch
+        if (tile == 10) return launch_tile<128, 128, 64, 64, A_PATCHES, 32, true>(stream, p, epilogue);
+        return launch_tile<128, 64, 64, 32, A_PATCHES, 32, true>(stream, p, epilogue);
     }
     switch (tile) {
         case 2: return launch_tile<256, 128, 128, 64, AMODE>(stream, p, epilogue);
