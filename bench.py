@@ -278,19 +278,12 @@ def main() -> None:
         # the gather, checked outside the timed region: EVERY slot r must hold what rank r says its records are (a broadcast
         # per rank: another collective than the one under test), and -- the batches start with the golden images -- the
         # golden labels in its first two entries
-        gather_ok = True
-        for r in range(world):
-            theirs = top1.clone()
-            dist.broadcast(theirs, src=r)
-            gather_ok = gather_ok and bool(torch.equal(gathered[r], theirs))
-            if golden is not None:
-                gather_ok = gather_ok and gathered[r, 0, :2].cpu().tolist() == golden.argmax(1).tolist()
-        flags = torch.tensor([1.0 if gather_ok else 0.0, -gold["max_abs_prob_err"] if gold else 0.0,
+        gather_ok = pkg.dp.verify_gather(top1, gathered, golden.argmax(1).tolist() if golden is not None else None)
+        flags = torch.tensor([-gold["max_abs_prob_err"] if gold else 0.0,
                               1.0 if (gold is None or gold["top1_match"]) else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)   # the worst of all ranks
-        gather_ok = bool(flags[0].item() == 1.0)
         if gold:
-            gold.update(max_abs_prob_err=float(-flags[1].item()), top1_match=bool(flags[2].item() == 1.0), ranks=world)
+            gold.update(max_abs_prob_err=float(-flags[0].item()), top1_match=bool(flags[1].item() == 1.0), ranks=world)
     handover = eng.handover_stats() if args.dtype == "f32" else None   # fp32 GEMM helper pieces of warm-up + timed steps
     kernel_steps = args.steps
     if args.lanes == 1 and not args.graph and not args.no_stage_brackets:

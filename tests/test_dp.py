@@ -29,7 +29,19 @@ def _worker(rank, world, port, n_images, out_dir):
     imgs = pkg.synth.make_images(cfg, n_images, 6)
     local, labels, probs = pkg.dp.forward_sharded(lambda x: po.forward(ocfg, x, W), imgs, rank, world)
     lo, hi = pkg.dp.shard_range(n_images, rank, world)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), local=local, labels=labels, probs=probs, lo=lo, hi=hi)
+    # the self-check bench.py runs on its RCCL gather (dp.verify_gather), here over gloo: right as it stands; wrong -- and reported
+    # wrong on BOTH ranks -- when one slot of one rank's buffer is corrupted, or when the known first labels are not there
+    import torch
+    packed = pkg.dp.pack_top1(torch.arange(4, dtype=torch.int32) + 10 * rank, torch.full((4,), 0.25 * (rank + 1)))
+    gathered = pkg.dp.gather_packed(packed)
+    good = pkg.dp.verify_gather(packed, gathered)
+    bad_copy = gathered.clone()
+    if rank == 1:
+        bad_copy[0, 0, 2] += 1
+    bad = pkg.dp.verify_gather(packed, bad_copy)
+    first = pkg.dp.verify_gather(packed, gathered, expect_first_labels=[0, 1])   # rank 1's slot starts with 10, 11
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), local=local, labels=labels, probs=probs, lo=lo, hi=hi,
+             verify=np.array([good, bad, first]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,6 +65,7 @@ def test_sharded_forward_and_top1_gather(tmp_path, n_images, oracle):
         assert np.array_equal(d["local"], full[lo:hi])          # every rank computed exactly its slice
         assert np.array_equal(d["labels"], full.argmax(1))       # and everybody holds the whole top-1 list
         assert np.array_equal(d["probs"], full.max(1))
+        assert d["verify"].tolist() == [True, False, False]       # the same verdicts on every rank
         seen += hi - lo
     assert seen == n_images
 

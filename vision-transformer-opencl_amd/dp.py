@@ -50,6 +50,27 @@ def gather_packed(packed, out=None, group=None):
     return out
 
 
+def verify_gather(packed, gathered, expect_first_labels=None, group=None) -> bool:
+    """Check the result of gather_packed on EVERY rank, with another collective than the one under test: slot r of `gathered`
+    must equal rank r's own `packed` records (one broadcast per rank), and -- when every rank's batch starts with images whose
+    labels are known (bench.py puts the golden images there) -- hold `expect_first_labels` in its first entries.  Returns the
+    verdict that is the same on all ranks (all_reduce MIN): True only if every slot was right everywhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    ok = tuple(gathered.shape) == (world,) + tuple(packed.shape)
+    for r in range(world if ok else 0):
+        theirs = packed.clone()
+        dist.broadcast(theirs, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+        ok = ok and bool(torch.equal(gathered[r], theirs))
+        if expect_first_labels is not None:
+            k = len(expect_first_labels)
+            ok = ok and gathered[r, 0, :k].cpu().tolist() == [int(v) for v in expect_first_labels]
+    flag = torch.tensor([1.0 if ok else 0.0], device=packed.device, dtype=torch.float32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() == 1.0)
+
+
 def gather_top1(labels, probs, counts=None, group=None):
     """All-gather the per-image top-1 records of every rank, in rank (= image) order.
 
