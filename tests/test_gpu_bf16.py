@@ -265,12 +265,13 @@ def test_ln_fold_is_invariant_to_lanes_chunks_and_pruning():
     imgs = synth.make_images(cfg, 11, 78)
     outs = {}
     for key, kw in {"base": dict(max_batch=16), "lanes3": dict(max_batch=16, lanes=3), "chunks": dict(max_batch=4, lanes=2),
+                    "split": dict(max_batch=16, lanes=2, lane_split=1),   # each lane's persistent launches on half of the CUs
                     "pruned": dict(max_batch=16, prune_last_layer=True), "kernels": dict(max_batch=16, ln_fold=-1)}.items():
         eng = B.Engine(cfg, dtype="bf16", **kw)
         eng.load_weights(W)
         outs[key] = eng.forward(imgs)
         eng.close()
-    for same in ("lanes3", "chunks", "pruned"):
+    for same in ("lanes3", "chunks", "split", "pruned"):
         assert np.array_equal(outs[same], outs["base"]), same
     assert np.array_equal(outs["base"][::-1], B_forward_reversed(cfg, W, imgs))
     d = float(np.abs(outs["kernels"] - outs["base"]).max())

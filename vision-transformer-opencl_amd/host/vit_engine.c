@@ -979,12 +979,21 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
      * Pieces of up to max_batch images flow through two staging slots: while the GPU computes piece i,
      * the host gathers the separately allocated images of piece i+1 into pinned memory and the copy
      * stream uploads them; the results of piece i-1 are scattered to the caller's rows meanwhile.
-     * A single chunk of >= 64 images is cut in two so that even the reference-sized call overlaps.
+     * Nothing overlaps the gather + upload of the FIRST piece, so it is a small one -- 64 images: the GPU starts after 39 MB
+     * instead of half the call, and the rest arrives behind its compute in pieces as large as the workspace allows (large
+     * pieces keep the GEMMs' tile walks long).  Measured through this entry at 256 images (one device, interleaved): first piece
+     * 128 (round 2: two halves) 71.7 ms, 96 71.0, 64 69.7, 48 70.3, 32 72.5 (its GEMMs fall into the small-batch tiles), 16 71.0;
+     * 1,024 images: 64 271.0 ms, 128 272.7.  Rows are bit-identical whatever the cut.
      */
-    int piece = chunk_limit(e);
-    if (n <= piece && n >= 64) piece = (n + 1) / 2;
-    const int np = (n + piece - 1) / piece;
-#define PIECE_N(i) ((i) == np - 1 ? n - (i) * piece : piece)
+    const int chunk = chunk_limit(e);
+    int first_n = n;
+    if (n >= 128) first_n = 64;
+    else if (n >= 64) first_n = (n + 1) / 2;
+    if (first_n > chunk) first_n = chunk;
+    if (first_n > n) first_n = n;
+    const int np = 1 + (n - first_n + chunk - 1) / chunk;
+#define PIECE_LO(i) ((i) == 0 ? 0 : ((i) >= np ? n : first_n + ((i) - 1) * chunk))
+#define PIECE_N(i) ((PIECE_LO((i) + 1) < n ? PIECE_LO((i) + 1) : n) - PIECE_LO(i))
     /* stage piece 0 */
     {
         int rc0 = stage_piece(e, 0, images, 0, PIECE_N(0), img);
@@ -1000,22 +1009,23 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
         if (e->opt.profile) e->pending_images += nb;
         if (k >= 1) { /* piece k-1 (slot b^1) is finished by now or soon: hand its rows back */
             HIP_TRY(e, vithip_event_sync(e->ev_done[b ^ 1]));
-            const int first = (k - 1) * piece;
+            const int first = PIECE_LO(k - 1);
             for (int i = 0; i < PIECE_N(k - 1); ++i)
                 memcpy(probs[first + i], e->pin_out[b ^ 1] + (size_t)i * NC, NC * sizeof(float));
         }
         if (k + 1 < np) { /* slot b^1 is free again (its H2D, compute and D2H are complete): refill it */
-            rc = stage_piece(e, b ^ 1, images, (k + 1) * piece, PIECE_N(k + 1), img);
+            rc = stage_piece(e, b ^ 1, images, PIECE_LO(k + 1), PIECE_N(k + 1), img);
             if (rc) return rc;
         }
     }
     {
-        const int b = (np - 1) & 1, first = (np - 1) * piece;
+        const int b = (np - 1) & 1, first = PIECE_LO(np - 1);
         HIP_TRY(e, vithip_event_sync(e->ev_done[b]));
         for (int i = 0; i < PIECE_N(np - 1); ++i)
             memcpy(probs[first + i], e->pin_out[b] + (size_t)i * NC, NC * sizeof(float));
     }
 #undef PIECE_N
+#undef PIECE_LO
     if (e->opt.profile) {
         int rc = collect_profile(e);
         if (rc) return rc;
