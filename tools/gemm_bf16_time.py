@@ -2,6 +2,9 @@
 """Time vithip_gemm_bf16 (product library, or the one VIT_HIP_LIBRARY names) at the ViT shapes.  GPU box only.
 
     python tools/gemm_bf16_time.py [batch] [b16|l16_384] [fold]     fold: the LayerNorm-folded forms (consumer qkv / fc1, producer outproj / fc2)
+
+VIT_TOOL_DATA=zeros|ones: operands without bit activity instead of random ones -- the same instructions and traffic at a lower
+power draw (the bf16 GEMMs run at the clock the power limit leaves them).
 """
 import ctypes as C, importlib, json, os, sys
 import numpy as np
@@ -20,10 +23,16 @@ SHAPES = {"qkv": (M, 3 * D, D, 0), "outproj": (M, D, D, 2), "fc1": (M, 4 * D, D,
 out = {}
 for name, (M_, N, K, epi) in SHAPES.items():
     rng = np.random.default_rng(0)
-    a = rng.integers(0x3c00, 0x4000, size=(M_, K), dtype=np.uint16)
-    a[::2] |= 0x8000
+    data = os.environ.get("VIT_TOOL_DATA", "random")
+    if data == "random":
+        a = rng.integers(0x3c00, 0x4000, size=(M_, K), dtype=np.uint16)
+        a[::2] |= 0x8000
+        w = B.to_bf16_bits(rng.uniform(-.05, .05, (N, K)).astype(np.float32))
+    else:
+        a = np.full((M_, K), 0x3f80 if data == "ones" else 0, np.uint16)
+        w = np.full((N, K), 0x3f80 if data == "ones" else 0, np.uint16)
     dA = B.DeviceArray.from_numpy(a)
-    dW = B.DeviceArray.from_numpy(B.to_bf16_bits(rng.uniform(-.05, .05, (N, K)).astype(np.float32)))
+    dW = B.DeviceArray.from_numpy(w)
     db = B.DeviceArray.from_numpy(rng.uniform(-.1, .1, (N,)).astype(np.float32))
     dC = B.DeviceArray((M_, N), np.float32 if epi == 2 else np.uint16)
     extra = []
@@ -41,4 +50,4 @@ for name, (M_, N, K, epi) in SHAPES.items():
     out[name] = {"ms": round(ms, 4), "tflops": round(2.0 * M_ * N * K / (ms * 1e-3) / 1e12, 1)}
     for d in [dA, dW, db, dC] + extra:
         d.free()
-print(json.dumps({"library": os.path.basename(B.LIB_PATH), "batch": batch, "model": model, "fold": fold, **out}))
+print(json.dumps({"library": os.path.basename(B.LIB_PATH), "data": os.environ.get("VIT_TOOL_DATA", "random"), "batch": batch, "model": model, "fold": fold, **out}))

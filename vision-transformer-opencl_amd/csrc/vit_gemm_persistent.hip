@@ -35,6 +35,12 @@
 // workspace (vithip_gemm_f32_workspace_stats): a recomputed piece costs x K-steps of one workgroup, never a wrong bit.
 #include "vit_gemm_common.hpp"
 
+// PG_DBG (timing-only switch-off builds for tools/gemm_f32_switchoff.py, results wrong by construction; 0 in every shipped object):
+// 1 no epilogue stores, 2 no staging loads inside the K loop, 3 no K-loop barrier, 4 no fragment reads, 5 no staging ds_writes, 6 = 2 + 5.
+// (What such builds measure is mostly the POWER of frozen operand data, not the removed instructions: DESIGN 4.1 item 11.)
+#ifndef PG_DBG
+#define PG_DBG 0
+#endif
 namespace vitgemm {
 
 constexpr int PBK = 32;           // K step
@@ -207,13 +213,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     auto restage_slot = [&](int q, int buf, int k0) {
         if (q < A_CHUNKS) {
             float *As = As0 + buf * BM * PLD;
-            *reinterpret_cast<f32x4 *>(As + (ld_row + q * ROWS_PER_PASS) * PLD + ld_kc) = a_stage[q];
-            a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_src[q], k0 * 4, 0));
+            if (PG_DBG != 5 && PG_DBG != 6) *reinterpret_cast<f32x4 *>(As + (ld_row + q * ROWS_PER_PASS) * PLD + ld_kc) = a_stage[q];
+            if (PG_DBG != 2 && PG_DBG != 6) a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_src[q], k0 * 4, 0));
         } else {
             const int qb = q - A_CHUNKS;
             float *Bs = Bs0 + buf * BN * PLD;
-            *reinterpret_cast<f32x4 *>(Bs + (ld_row + qb * ROWS_PER_PASS) * PLD + ld_kc) = b_stage[qb];
-            b_stage[qb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_src[qb], k0 * 4, 0));
+            if (PG_DBG != 5 && PG_DBG != 6) *reinterpret_cast<f32x4 *>(Bs + (ld_row + qb * ROWS_PER_PASS) * PLD + ld_kc) = b_stage[qb];
+            if (PG_DBG != 2 && PG_DBG != 6) b_stage[qb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_src[qb], k0 * 4, 0));
         }
     };
 
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     advance_load_cursor();
     __syncthreads();
     read_frags(0, 0, 0);
+    if (PG_DBG == 4) read_frags(0, 1, 1);
 
     if constexpr (STAMP) st_loop0 = __builtin_amdgcn_s_memtime();
     int cur = 0;
@@ -323,11 +330,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         const int k_ahead = k_l * PBK;  // offset of the step the restage loads fetch (step g + 2)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            if (c + 1 < NC) read_frags(cur, c + 1, (c + 1) & 1);
+            if (c + 1 < NC && PG_DBG != 4) read_frags(cur, c + 1, (c + 1) & 1);
             if (c == NC - 1) {
                 // every wave has read buffer `cur` and written buffer `cur^1` (chunk 0): swap point.
-                __syncthreads();
-                read_frags(cur ^ 1, 0, NC & 1);  // first fragments of step g + 1 (maybe the next tile)
+                if (PG_DBG != 3) __syncthreads();
+                if (PG_DBG != 4) read_frags(cur ^ 1, 0, NC & 1);  // first fragments of step g + 1 (maybe the next tile)
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
             unsigned long long e0 = 0;
             if constexpr (STAMP) e0 = __builtin_amdgcn_s_memtime();
             if (SK && out_c >= 0) park(out_c);
-            else epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h);
+            else if (PG_DBG != 1 || p.M < 0) epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h);  // (M < 0: never; keeps the MFMAs alive)
             if constexpr (STAMP) st_epi += __builtin_amdgcn_s_memtime() - e0;
             if (++seg_c < nseg) begin_segment(seg_c);
         }
