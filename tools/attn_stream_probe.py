@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time and stamp the streamed bf16 attention kernel at ViT-L/16-384 (probe build for the stamps). GPU box only."""
+"""Time and stamp the streamed bf16 attention kernel at ViT-L/16-384 (probe build for the stamps). GPU box only.
+VIT_TOOL_DATA=zeros: an all-zero qkv (the same instructions at a lower power draw: is the kernel clock-limited?)."""
 import importlib, json, os, sys, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +11,8 @@ n, T, heads = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) 
 D = heads * 64
 rng = np.random.default_rng(0)
 vals = rng.uniform(-1.5, 1.5, (n * T, 3 * D)).astype(np.float32)
+if os.environ.get("VIT_TOOL_DATA") == "zeros":
+    vals[:] = 0
 dq = B.DeviceArray.from_numpy(B.to_bf16_bits(vals))
 vals[:, :D] *= np.float32(B.QSCALE)          # what the engine's folded in_proj writes into the Q columns
 dqs = B.DeviceArray.from_numpy(B.to_bf16_bits(vals))

@@ -1,0 +1,94 @@
+// What does the chip sustain on fp32 MFMAs alone, by instruction shape and operand activity?  512 workgroups x 4 waves (two waves
+// per SIMD, as the GEMM), 64 accumulator registers per wave, eight A and eight B operand registers cycled as a K loop would:
+//   v_mfma_f32_32x32x2_f32 : 2 x 2 accumulators of 16 registers -- per 4096 flop 2 operand + 32 accumulator register accesses
+//   v_mfma_f32_16x16x4_f32 : 4 x 4 accumulators of 4 registers  -- per 4096 flop 4 operand + 16 accumulator register accesses
+// (both add their k-products in the same order: tools/probes/mfma_order_probe.hip) on random and on all-zero operands.
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_power_probe.hip -o gpurun_out/mfma_power_probe && ./gpurun_out/mfma_power_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void mfma_loop(const float *src, float *dst, int iters) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = src[(t * 16 + i) & 0xfffff];
+        b[i] = src[(t * 16 + 8 + i) & 0xfffff] * 0.01f;
+    }
+    if constexpr (SHAPE == 32) {
+        f32x16 acc[2][2] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(s + 4 * i) & 7], b[(s + 4 * j) & 7], acc[i][j], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) s += acc[i][j][v];
+        dst[t] = s;
+    } else {
+        f32x4 acc[4][4] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)   // the same 32 x 4096 flop per iteration as above: 4 x 16 instructions of 2048
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(s + 2 * i) & 7], b[(s + 2 * j) & 7], acc[i][j], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) s += acc[i][j][v];
+        dst[t] = s;
+    }
+}
+
+template <int SHAPE>
+static double run(const float *src, float *dst, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_loop<SHAPE>, dim3(512), dim3(256), 0, 0, src, dst, iters / 4);
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(mfma_loop<SHAPE>, dim3(512), dim3(256), 0, 0, src, dst, iters);
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) { printf("HIP error\n"); exit(2); }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 3.0 * 512 * 4 * (double)iters * 32 * 4096;
+    return flop / (ms * 1e-3) / 1e12;
+}
+
+int main() {
+    const size_t n = 1 << 20;
+    std::vector<float> h(n);
+    srand(11);
+    for (auto &x : h) x = rand() / (float)RAND_MAX * 2.f - 1.f;
+    float *rnd, *zero, *dst;
+    hipMalloc(&rnd, n * 4); hipMalloc(&zero, n * 4); hipMalloc(&dst, 512 * 256 * 4);
+    hipMemcpy(rnd, h.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemset(zero, 0, n * 4);
+    const int iters = 20000;   // ~ 35 ms per launch
+    for (int round = 0; round < 3; ++round) {
+        const double r32 = run<32>(rnd, dst, iters), r16 = run<16>(rnd, dst, iters), z32 = run<32>(zero, dst, iters), z16 = run<16>(zero, dst, iters);
+        printf("{\"round\": %d, \"tflops\": {\"32x32x2_random\": %.1f, \"16x16x4_random\": %.1f, \"32x32x2_zeros\": %.1f, \"16x16x4_zeros\": %.1f}}\n",
+               round, r32, r16, z32, z16);
+    }
+    return 0;
+}
