@@ -60,6 +60,78 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const float *src, float *dst
     }
 }
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// bf16: 16x16x32 (4 x 4 accumulators of 4 registers) or 32x32x16 (2 x 2 of 16); eight A and eight B operand quads cycled
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void mfma_bf16_loop(const float *src, float *dst, int iters) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    bf16x8 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32x4 ua, ub;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // two bf16 per word: the upper halves of two random floats (sign, exponent, 7 mantissa bits)
+            const unsigned x = __builtin_bit_cast(unsigned, src[(t * 64 + i * 8 + e) & 0xfffff]), y = __builtin_bit_cast(unsigned, src[(t * 64 + i * 8 + 4 + e) & 0xfffff]);
+            ua[e] = (x >> 16) | (y & 0xffff0000u);
+            ub[e] = (y >> 16) | (x & 0xffff0000u);
+        }
+        a[i] = __builtin_bit_cast(bf16x8, ua);
+        b[i] = __builtin_bit_cast(bf16x8, ub);
+    }
+    float s = 0.f;
+    if constexpr (SHAPE == 16) {
+        f32x4 acc[4][4] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(k + 2 * i) & 7], b[(k + 2 * j) & 7], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) s += acc[i][j][v];
+    } else {
+        f32x16 acc[2][2] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(k + 4 * i) & 7], b[(k + 4 * j) & 7], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) s += acc[i][j][v];
+    }
+    dst[t] = s;
+}
+
+template <int SHAPE>
+static double run_bf16(const float *src, float *dst, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_bf16_loop<SHAPE>, dim3(512), dim3(256), 0, 0, src, dst, iters / 4);
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(mfma_bf16_loop<SHAPE>, dim3(512), dim3(256), 0, 0, src, dst, iters);
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) { printf("HIP error\n"); exit(2); }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 3.0 * 512 * 4 * (double)iters * 64 * 16384;   // 64 x 16x16x32 (= 32 x 32x32x16) per iteration
+    return flop / (ms * 1e-3) / 1e12;
+}
+
 template <int SHAPE>
 static double run(const float *src, float *dst, int iters) {
     hipEvent_t e0, e1;
@@ -89,6 +161,12 @@ int main() {
         const double r32 = run<32>(rnd, dst, iters), r16 = run<16>(rnd, dst, iters), z32 = run<32>(zero, dst, iters), z16 = run<16>(zero, dst, iters);
         printf("{\"round\": %d, \"tflops\": {\"32x32x2_random\": %.1f, \"16x16x4_random\": %.1f, \"32x32x2_zeros\": %.1f, \"16x16x4_zeros\": %.1f}}\n",
                round, r32, r16, z32, z16);
+    }
+    for (int round = 0; round < 3; ++round) {
+        const int it16 = 80000;   // ~ 35 ms per launch at 2.4 PFLOP/s
+        const double r16 = run_bf16<16>(rnd, dst, it16), r32 = run_bf16<32>(rnd, dst, it16), z16 = run_bf16<16>(zero, dst, it16), z32 = run_bf16<32>(zero, dst, it16);
+        printf("{\"round\": %d, \"bf16_tflops\": {\"16x16x32_random\": %.0f, \"32x32x16_random\": %.0f, \"16x16x32_zeros\": %.0f, \"32x32x16_zeros\": %.0f}}\n",
+               round, r16, r32, z16, z32);
     }
     return 0;
 }
