@@ -16,6 +16,8 @@ Extra objects in the line:
                 on every rank, at any N (1e-4 fp32 / 2e-2 bf16, identical top-1); with N > 1 rank 0 also checks every rank's
                 slot of the RCCL gather (against a broadcast of that rank's records and against the golden labels).
                 Any failure sets "ok": false and the exit code.
+  roofline.clock_limit_probe   N = 1: the dominant GEMM's launch shape timed on random and on all-zero operands (same instructions,
+                same traffic): how much of the gap to the roofline is the clock the power limit leaves, measured on this device.
   c_surface     N = 1: the same batch through vit_engine_forward_host -- what ViT_opencl(ImageData*, Network*, float**) does
                 underneath (separately allocated host images in, host probability rows out: H2D and D2H inside the time,
                 Main.c:55-60 times exactly that call).  Never `value`.
@@ -108,6 +110,69 @@ def pmc_mfma(kernel, tag, batch):
     return float(r["mfma_busy_percent"]), float(r["clock_ghz_from_gui_active"])
 
 
+def clock_limit_probe(binding, torch, dev, cfg, batch, dtype):
+    """The same GEMM launch (the dominant kernel's shape, product library, default stream) on random and on all-zero operands:
+    identical instructions and memory traffic, different bit activity.  The chip runs these kernels at the clock its power limit
+    leaves, so the second figure is what the schedule delivers when the clock is not what gives."""
+    import ctypes as C
+    L = binding.lib()
+    M = batch * cfg.tokens
+    D, H = cfg.embed_dim, cfg.hidden_dim
+
+    def timed(fn, reps=4, warm=2):
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        L.vithip_event_create(C.byref(e0)); L.vithip_event_create(C.byref(e1))
+        for _ in range(warm):
+            fn()
+        L.vithip_event_record(e0, None)
+        for _ in range(reps):
+            fn()
+        L.vithip_event_record(e1, None)
+        L.vithip_event_sync(e1)
+        ms = C.c_float()
+        L.vithip_event_elapsed_ms(C.byref(ms), e0, e1)
+        return ms.value / reps
+
+    torch.cuda.synchronize(dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    out = {}
+    if dtype == "f32":      # fc2: [M, H] x [D, H]^T + bias + residual, helper pieces on (what the engine launches)
+        N, K, kernel = D, H, "gemm_f32_nt_persistent_kernel<EPI_BIAS_RESIDUAL>"
+        ws = binding.gemm_workspace()
+        bias = torch.zeros(N, device=dev)
+        Cbuf = torch.empty((M, N), device=dev)
+        for name in ("random", "zero"):
+            A = (torch.rand((M, K), device=dev, generator=g) * 2 - 1) if name == "random" else torch.zeros((M, K), device=dev)
+            W = (torch.rand((N, K), device=dev, generator=g) * 0.1 - 0.05) if name == "random" else torch.zeros((N, K), device=dev)
+            R = (torch.rand((M, N), device=dev, generator=g) * 2 - 1) if name == "random" else torch.zeros((M, N), device=dev)
+            torch.cuda.synchronize(dev)
+            ga = binding.CGemmArgs(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), R.data_ptr(), N, Cbuf.data_ptr(), N, M, N, K,
+                                   binding.EPI_BIAS_RESIDUAL, 0, 0, ws, 0)
+            ms = min(timed(lambda: binding.hip_check(L.vithip_gemm_f32(None, C.byref(ga)))) for _ in range(2))
+            out[name] = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+            del A, W, R
+        L.vithip_gemm_f32_workspace_destroy.argtypes = [C.c_void_p]
+        L.vithip_gemm_f32_workspace_destroy(ws)
+    else:                   # QKV: [M, D] x [3D, D]^T + bias -> bf16 (the plain form: no LayerNorm-fold operands)
+        N, K, kernel = 3 * D, D, "gemm_bf16_pp_kernel<BF16>"
+        L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(binding.CGemmBf16Args)]
+        bias = torch.zeros(N, device=dev)
+        Cbuf = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+        for name in ("random", "zero"):
+            A = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16) if name == "random" else torch.zeros((M, K), device=dev, dtype=torch.bfloat16)
+            W = (torch.randn((N, K), device=dev, generator=g) * 0.03).to(torch.bfloat16) if name == "random" else torch.zeros((N, K), device=dev, dtype=torch.bfloat16)
+            torch.cuda.synchronize(dev)
+            ga = binding.CGemmBf16Args(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), None, N, Cbuf.data_ptr(), N, M, N, K, 0, 0, 0, 0,
+                                       None, None, None, 0, None)
+            ms = min(timed(lambda: binding.hip_check(L.vithip_gemm_bf16(None, C.byref(ga)))) for _ in range(2))
+            out[name] = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+            del A, W
+    return {"kernel": kernel, "shape_mnk": [M, N, K], "random_operands_tflops": round(out["random"], 1),
+            "zero_operands_tflops": round(out["zero"], 1), "zero_over_random": round(out["zero"] / out["random"], 4),
+            "note": "one launch shape of the product library timed on both operand sets (HIP events, default stream): same instructions "
+                    "and traffic, the difference is clock the power limit takes back on busy operands"}
+
+
 def stage_macs(cfg, batch):
     T, D, H = cfg.tokens, cfg.embed_dim, cfg.hidden_dim
     M = batch * T
@@ -159,6 +224,8 @@ def main() -> None:
                     help="BASELINE.json configs[i] preset: 1 = fp32 batch 256 (the metric, the default), 2 = bf16 batch 2048, "
                          "3 = bf16 2048 per GPU (global 16384 at --gpus 8), 4 = ViT-L/16-384 bf16 batch 1024")
     ap.add_argument("--no-c-surface", action="store_true", help="skip the host-pointer (ViT_opencl-shaped) timing after the timed region")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip roofline.clock_limit_probe (the dominant GEMM shape once on random and once on all-zero operands)")
     ap.add_argument("--lane-split", type=int, default=-1, choices=(-1, 0, 1),
                     help="bf16 with lanes > 1: 1 = every lane's persistent launches take 1/lanes of the CUs (lanes side by side), "
                          "0 = whole-chip launches that alternate; -1 = the default for the dtype")
@@ -439,6 +506,10 @@ def main() -> None:
                      "sample": f"best of {reps} calls of vit_engine_forward_host on the timed batch ({B} images, pageable host "
                                "memory, pinned double-buffered staging inside the call)",
                      "bit_identical_to_device_path": same}
+
+    # ---- how much of the gap to the roofline is clock (N = 1): the dominant GEMM's shape on busy and on quiet operands ------------
+    if rank == 0 and world == 1 and not args.no_clock_probe and not args.prune_last_layer:
+        roofline["clock_limit_probe"] = clock_limit_probe(binding, torch, dev, cfg, B if args.lanes == 1 else B // args.lanes, args.dtype)
 
     ok = (gather_ok is not False) and (gold is None or (gold["top1_match"] and gold["max_abs_prob_err"] <= tol))
     if parity is not None:

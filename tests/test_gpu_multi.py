@@ -180,6 +180,8 @@ def test_bench_rank_takes_the_rccl_path_at_world_size_one():
     assert rec["golden"]["top1_match"] and rec["golden"]["max_abs_prob_err"] <= 1e-4 and rec["golden"]["ranks"] == 1
     assert rec["c_surface"]["bit_identical_to_device_path"] and rec["c_surface"]["value"] > 0
     assert rec["roofline"]["gemm_handover"] is not None
+    probe = rec["roofline"]["clock_limit_probe"]      # the dominant GEMM's shape on random and on all-zero operands
+    assert probe["shape_mnk"] == [16 * 197, 768, 3072] and probe["random_operands_tflops"] > 0 and probe["zero_operands_tflops"] > 0
 
 
 def test_bench_config3_preset_is_bf16_2048_per_gpu():
@@ -192,6 +194,9 @@ def test_bench_config3_preset_is_bf16_2048_per_gpu():
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert rec["dtype"] == "bf16" and rec["config"]["batch_per_gpu"] == 2048 and "configs[3]" in rec["config"]["workload"]
     assert rec["ok"] is True and rec["golden"]["top1_match"] and rec["golden"]["max_abs_prob_err"] <= 2e-2
+    # at full size the same bf16 QKV launch is clearly faster on quiet operands: these kernels run at the power limit's clock
+    probe = rec["roofline"]["clock_limit_probe"]
+    assert probe["shape_mnk"] == [1024 * 197, 2304, 768] and probe["zero_over_random"] > 1.02, probe
 
 
 @pytest.mark.parametrize("n_images", [6, 5])
