@@ -25,8 +25,9 @@ def child():
     rng = np.random.default_rng(0)
     out = {}
     for name, (M, N, K, epi) in SHAPES.items():
-        dA = B.DeviceArray.from_numpy(rng.uniform(-1, 1, (M, K)).astype(np.float32))
-        dW = B.DeviceArray.from_numpy(rng.uniform(-.05, .05, (N, K)).astype(np.float32))
+        zero = os.environ.get("VIT_TOOL_DATA") == "zeros"   # quiet operands: no power effect, the structure alone
+        dA = B.DeviceArray.from_numpy(np.zeros((M, K), np.float32) if zero else rng.uniform(-1, 1, (M, K)).astype(np.float32))
+        dW = B.DeviceArray.from_numpy(np.zeros((N, K), np.float32) if zero else rng.uniform(-.05, .05, (N, K)).astype(np.float32))
         db = B.DeviceArray.from_numpy(rng.uniform(-.1, .1, (N,)).astype(np.float32))
         dC = B.DeviceArray((M, N))
         dR = B.DeviceArray((M, N))
@@ -44,6 +45,8 @@ if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     names = {"pg0": "product", "pg1": "no epilogue", "pg2": "no staging loads", "pg3": "no barrier", "pg4": "no fragment reads",
              "pg5": "no ds_writes", "pg6": "no staging at all"}
+    if len(sys.argv) > 2:
+        names = {}
     names.update({a: a for a in sys.argv[2:]})   # further A/B libraries: build/dbg/libvit_<name>.so
     for r in range(rounds):
         for n, what in names.items():

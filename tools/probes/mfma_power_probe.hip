@@ -60,6 +60,87 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const float *src, float *dst
     }
 }
 
+// The fp32 GEMM's inner loop without its global side: operand fragments come from LDS (random contents, 16 ds_read_b128 per 32 k
+// and wave as in csrc/vit_gemm_persistent.hip), 64 accumulator registers, two waves per SIMD.  Same LDS bytes and flops either way:
+//   SHAPE 32: per 8 k   2 + 2 fragment reads feed 16 v_mfma_f32_32x32x2_f32
+//   SHAPE 16: per 16 k  4 + 4 fragment reads feed 64 v_mfma_f32_16x16x4_f32
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void gemm_like_loop(const float *src, float *dst, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];   // 64 KB
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 16384; i += 256) lds[i] = src[(blockIdx.x * 16384 + i) & 0xfffff];
+    __syncthreads();
+    const f32x4 *frag = reinterpret_cast<const f32x4 *>(lds);   // 4096 float4
+    float s = 0.f;
+    if constexpr (SHAPE == 32) {
+        f32x16 acc[2][2] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 af[2], bf[2];
+                const int base = (it * 67 + c * 1031 + (t >> 6) * 257) & 4095;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = frag[(base + i * 64 + lane) & 4095];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = frag[(base + 2048 + j * 64 + lane) & 4095];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k], bf[j][k] * 0.01f, acc[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) s += acc[i][j][v];
+    } else {
+        f32x4 acc[4][4] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 af[4], bf[4];
+                const int base = (it * 67 + c * 1031 + (t >> 6) * 257) & 4095;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = frag[(base + i * 64 + lane) & 4095];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = frag[(base + 2048 + j * 64 + lane) & 4095];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][k], bf[j][k] * 0.01f, acc[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) s += acc[i][j][v];
+    }
+    dst[blockIdx.x * 256 + t] = s;
+}
+
+template <int SHAPE>
+static double run_gemm_like(const float *src, float *dst, int iters) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(gemm_like_loop<SHAPE>, dim3(512), dim3(256), 0, 0, src, dst, iters / 4);
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(gemm_like_loop<SHAPE>, dim3(512), dim3(256), 0, 0, src, dst, iters);
+    (void)hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) { printf("HIP error\n"); exit(2); }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 3.0 * 512 * 4 * (double)iters * 262144.0;
+    return flop / (ms * 1e-3) / 1e12;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -160,6 +241,12 @@ int main() {
     for (int round = 0; round < 3; ++round) {
         const double r32 = run<32>(rnd, dst, iters), r16 = run<16>(rnd, dst, iters), z32 = run<32>(zero, dst, iters), z16 = run<16>(zero, dst, iters);
         printf("{\"round\": %d, \"tflops\": {\"32x32x2_random\": %.1f, \"16x16x4_random\": %.1f, \"32x32x2_zeros\": %.1f, \"16x16x4_zeros\": %.1f}}\n",
+               round, r32, r16, z32, z16);
+    }
+    for (int round = 0; round < 3; ++round) {
+        const int itg = 2500;   // x 262144 flop per wave and iteration
+        const double r32 = run_gemm_like<32>(rnd, dst, itg), r16 = run_gemm_like<16>(rnd, dst, itg), z32 = run_gemm_like<32>(zero, dst, itg), z16 = run_gemm_like<16>(zero, dst, itg);
+        printf("{\"round\": %d, \"fragments_from_lds_tflops\": {\"32x32x2_random\": %.1f, \"16x16x4_random\": %.1f, \"32x32x2_zeros\": %.1f, \"16x16x4_zeros\": %.1f}}\n",
                round, r32, r16, z32, z16);
     }
     for (int round = 0; round < 3; ++round) {
