@@ -332,6 +332,7 @@ def main() -> None:
     fence()
     dt = time.perf_counter() - t0
     gather_ok = None
+    per_rank_ms = None
     tol = 1e-4 if args.dtype == "f32" else 2e-2
     gold = None
     if golden is not None:  # rows 0-1 of the timed steps' output against the reference's probabilities, on this rank
@@ -340,6 +341,9 @@ def main() -> None:
                 "top1_match": bool((got2.argmax(1) == golden.argmax(1)).all()), "tolerance": tol}
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                      # each rank's own time: devices of one node differ by a few per cent in the
+        per_rank_ms = [round(1e3 * float(x.item()) / args.steps, 3) for x in every]   # clock they hold, and the slowest one is `value`
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # the gather, checked outside the timed region: EVERY slot r must hold what rank r says its records are (a broadcast
@@ -518,7 +522,7 @@ def main() -> None:
         info = binding.device_info(local_rank)
         print(json.dumps({
             "metric": METRIC, "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": (f"{'ViT-B/16 224x224' if args.model == 'b16' else 'ViT-L/16 384x384'} "

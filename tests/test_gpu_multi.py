@@ -175,6 +175,7 @@ def test_bench_rank_takes_the_rccl_path_at_world_size_one():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["top1_gather"] == "rccl all_gather, 8 B per image"
     assert rec["value"] > 0
+    assert len(rec["per_rank_ms_per_step"]) == 1 and abs(rec["per_rank_ms_per_step"][0] - rec["ms_per_step"]) < 1e-2   # max over ranks
     # the line validates itself: golden rows inside the timed batch, every gather slot checked, the host-pointer surface
     assert rec["ok"] is True
     assert rec["golden"]["top1_match"] and rec["golden"]["max_abs_prob_err"] <= 1e-4 and rec["golden"]["ranks"] == 1
