@@ -162,7 +162,7 @@ def clock_limit_probe(binding, torch, dev, cfg, batch, dtype):
             A = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16) if name == "random" else torch.zeros((M, K), device=dev, dtype=torch.bfloat16)
             W = (torch.randn((N, K), device=dev, generator=g) * 0.03).to(torch.bfloat16) if name == "random" else torch.zeros((N, K), device=dev, dtype=torch.bfloat16)
             torch.cuda.synchronize(dev)
-            ga = binding.CGemmBf16Args(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), None, N, Cbuf.data_ptr(), N, M, N, K, 0, 0, 0, 0,
+            ga = binding.CGemmBf16Args(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), None, N, Cbuf.data_ptr(), N, M, N, K, 0, 0,
                                        None, None, None, 0, None)
             ms = min(timed(lambda: binding.hip_check(L.vithip_gemm_bf16(None, C.byref(ga)))) for _ in range(2))
             out[name] = 2.0 * M * N * K / (ms * 1e-3) / 1e12
@@ -219,16 +219,13 @@ def main() -> None:
                     help="vit_engine_options.use_graph: replay the forward as one hipGraph (needs --lanes 1; small batches)")
     ap.add_argument("--ln-fold", type=int, default=0, choices=(-1, 0, 1),
                     help="bf16: fold the encoder LayerNorms into the GEMMs either side (0 auto = on, -1 off: LayerNorm kernels)")
-    ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: 0 auto, 1 128x128, 2 256x128, 3 128x64")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: vithip_gemm_args.tile of every fp32 GEMM (0 auto; 6..12, include/vit_hip_kernels.h)")
     ap.add_argument("--config", type=int, default=0, choices=(0, 1, 2, 3, 4),
                     help="BASELINE.json configs[i] preset: 1 = fp32 batch 256 (the metric, the default), 2 = bf16 batch 2048, "
                          "3 = bf16 2048 per GPU (global 16384 at --gpus 8), 4 = ViT-L/16-384 bf16 batch 1024")
     ap.add_argument("--no-c-surface", action="store_true", help="skip the host-pointer (ViT_opencl-shaped) timing after the timed region")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip roofline.clock_limit_probe (the dominant GEMM shape once on random and once on all-zero operands)")
-    ap.add_argument("--lane-split", type=int, default=-1, choices=(-1, 0, 1),
-                    help="bf16 with lanes > 1: 1 = every lane's persistent launches take 1/lanes of the CUs (lanes side by side), "
-                         "0 = whole-chip launches that alternate; -1 = the default for the dtype")
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes from this process even for --gpus 1 (N > 1 always does when not "
                          "already launched): exercises the launcher and the RCCL gather at world size 1")
@@ -278,8 +275,7 @@ def main() -> None:
     # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
     # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
     eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1 and not args.graph and not args.no_stage_brackets), lanes=args.lanes,
-                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph, gemm_tile=args.gemm_tile, ln_fold=args.ln_fold,
-                         lane_split=max(args.lane_split, 0))
+                         dtype=args.dtype, prune_last_layer=args.prune_last_layer, use_graph=args.graph, gemm_tile=args.gemm_tile, ln_fold=args.ln_fold)
     eng.load_weights(weights)
 
     # synthetic batch, generated on the host with the repo PRNG for the first images (so that the

@@ -55,9 +55,6 @@ typedef struct {
                       * the fp32 path keeps the reference's operation order. */
     int gemm_handover_test; /* testing: vithip_gemm_args.handover_test for every fp32 GEMM (1 = helper pieces arrive too late and
                              * every owner computes its whole tile; results must not change) */
-    int lane_split;  /* bf16 engines with lanes > 1: 1 = every lane's persistent launches (GEMMs, attention) take 1/lanes of the CUs, so
-                      * that the lanes run side by side all the time -- one lane's HBM-bound phases beside another's matrix phases --
-                      * instead of alternating whole-chip launches; 0 = every launch may take the whole device */
 } vit_engine_options;
 
 enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };

@@ -95,10 +95,9 @@ typedef struct {
     int M, N, K;
     int epilogue;
     /* tuning, per call (the library keeps no process-wide tuning state); 0 = auto:
-     * tile: 0 = auto (128x128 tile, K step 32: persistent walk for the bias and bias+GELU epilogues, one pipelined tile
-     *   per workgroup for bias+residual; 128x64 tiles for small problems); classic loop: 1 = 128x128, 2 = 256x128,
-     *   3 = 128x64, 4 = 128x128 K16, 5 = 128x64 K16; pipelined loop: 10 = 128x128, 6 = 128x128 K16, 7 = 256x128,
-     *   8 = 128x64, 11 = 64x64, 12 = 32x32 on 16x16x4 MFMA (K % 128 == 0; auto for problems that leave CUs idle); 9 = persistent 128x128.
+     * tile: 0 = auto (persistent walk of 128x128 tiles for problems of many tiles, 128x64 / 64x64 / 32x32 tiles as the problem
+     *   shrinks); one software-pipelined tile per workgroup: 10 = 128x128, 6 = 128x128 with K step 16, 7 = 256x128, 8 = 128x64,
+     *   11 = 64x64; 12 = 32x32 on 16x16x4 MFMA (K % 128 == 0); 9 = persistent 128x128.  All of them give the same bits.
      * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default 8; 1 = plain N-fastest order). */
     int tile, group_m;
     /* optional scratch: the HANDLE made by vithip_gemm_f32_workspace_create() on the device the launch runs on (one per
@@ -131,12 +130,9 @@ typedef struct {
     void *C; int ldc;                   /* bf16 (EPI_BF16, EPI_BF16_GELU) or fp32 (EPI_F32_RESIDUAL) */
     int M, N, K;                        /* K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0 */
     int epilogue;
-    /* tuning/testing, per call; all 0 = default:
-     * variant: 0 auto (ping-pong kernel whenever K >= 128), 1 two-stage kernel (vit_gemm_bf16.hip), 2 ping-pong kernel
-     *   (vit_gemm_bf16_pp.hip; invalid-value error when K < 128);
-     * two_barriers: barrier schedule of the ping-pong kernel, 0 = one barrier per phase and wave (default), 1 = two;
-     * stagger: start-up skew between its persistent workgroups, units of 512 cycles per position in the XCD (0..64). */
-    int variant, two_barriers, stagger;
+    /* testing, per call: 0 auto (ping-pong kernel whenever K >= 128), 1 two-stage kernel (vit_gemm_bf16.hip: the fallback for
+     * K < 128), 2 ping-pong kernel (vit_gemm_bf16_pp.hip; invalid-value error when K < 128) */
+    int variant;
     /* LayerNorm folded into the GEMMs either side of it (all NULL = off; ping-pong kernel only, i.e. K >= 128):
      * producer, EPI_F32_RESIDUAL with x16 and row_partials set: besides C the epilogue stores bf16(C) to x16 [M][ldx16]
      *   (ldx16 % 8 == 0, 16-byte aligned) and the partial (sum, sum of squares) of every row over every 64-column strip to
@@ -147,10 +143,6 @@ typedef struct {
     const float *ln_rows, *ln_colsum;
     unsigned short *x16; int ldx16;
     float *row_partials;
-    /* cap on the persistent workgroups of the launch (0 = one per CU): an engine that runs L lanes gives every lane's launches
-     * 1/L of the CUs, so that one lane's HBM-bound phases (residual epilogues, attention) run beside another lane's matrix phases
-     * instead of each launch waiting for the whole chip */
-    int max_workgroups;
 } vithip_gemm_bf16_args;
 /* C = epilogue(A . W^T + bias) on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16 in the ping-pong kernel,
  * v_mfma_f32_32x32x16_bf16 in the two-stage one), fp32 accumulate.  BF16_GELU rounds gelu(acc + bias) to bf16 (a
@@ -196,9 +188,10 @@ int vithip_attention_f32_rows(vithip_stream_t stream, const float *qkv, float *o
 int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images,
                                  int tokens, int heads, int q_rows);
 /* As vithip_attention_bf16io (q_rows = tokens) / _rows, for Q columns that already hold VITHIP_QSCALE * q.  For the streamed
- * kernel (225..704 tokens) this removes the scale-and-subtract of every score: the score accumulators start at -max. */
+ * kernel (225..704 tokens) this removes the scale-and-subtract of every score: the score accumulators start at -max; the
+ * resident kernel (up to 224) and the chunked one (beyond 704) take the factor 1 in place of VITHIP_QSCALE. */
 int vithip_attention_bf16io_qscaled(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images,
-                                    int tokens, int heads, int q_rows, int max_workgroups /* 0 = as many as the device holds */);
+                                    int tokens, int heads, int q_rows);
 /* Patch embedding on the bf16 matrix pipe (same result layout as vithip_patch_embed_f32: x[n][tokens][D] fp32 with
  * class token and pos_emb applied; ViT_seq.c:25-101): the images are cut into bf16 patch rows
  * (patches16: workspace of n * (img/patch)^2 * chans*patch^2 bf16), multiplied with the bf16 conv weight

@@ -40,8 +40,11 @@ def _worker(rank, world, port, n_images, out_dir):
         bad_copy[0, 0, 2] += 1
     bad = pkg.dp.verify_gather(packed, bad_copy)
     first = pkg.dp.verify_gather(packed, gathered, expect_first_labels=[0, 1])   # rank 1's slot starts with 10, 11
+    # a buffer of the wrong shape on ONE rank: that rank must still take part in every collective of the check (or the other
+    # would wait in its broadcasts for ever) and both must hear "wrong"
+    shape = pkg.dp.verify_gather(packed, gathered[:, :, :3] if rank == 1 else gathered)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), local=local, labels=labels, probs=probs, lo=lo, hi=hi,
-             verify=np.array([good, bad, first]))
+             verify=np.array([good, bad, first, shape]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,7 +68,7 @@ def test_sharded_forward_and_top1_gather(tmp_path, n_images, oracle):
         assert np.array_equal(d["local"], full[lo:hi])          # every rank computed exactly its slice
         assert np.array_equal(d["labels"], full.argmax(1))       # and everybody holds the whole top-1 list
         assert np.array_equal(d["probs"], full.max(1))
-        assert d["verify"].tolist() == [True, False, False]       # the same verdicts on every rank
+        assert d["verify"].tolist() == [True, False, False, False]  # the same verdicts on every rank
         seen += hi - lo
     assert seen == n_images
 

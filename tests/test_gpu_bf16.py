@@ -23,14 +23,13 @@ def test_f32_to_bf16_matches_round_to_nearest_even():
     assert np.array_equal(B.f32_to_bf16_device(x), B.to_bf16_bits(x))
 
 
-@pytest.fixture(params=[(1, True), (2, True), (2, False)], ids=["two-stage", "ping-pong", "ping-pong-two-barriers"])
+@pytest.fixture(params=[1, 2], ids=["two-stage", "ping-pong"])
 def variant(request, monkeypatch):
-    """Both bf16 GEMM kernels behind vithip_gemm_bf16 (0 = auto picks ping-pong whenever K >= 128), the ping-pong one
-    with both of its barrier schedules -- selected per call (vithip_gemm_bf16_args.variant / .two_barriers): the
-    library has no process-wide tuning state."""
-    v, one_barrier = request.param
+    """Both bf16 GEMM kernels behind vithip_gemm_bf16 (0 = auto picks ping-pong whenever K >= 128; the two-stage kernel is the
+    fallback for K < 128) -- selected per call (vithip_gemm_bf16_args.variant): the library has no process-wide tuning state."""
+    v = request.param
     plain = B.gemm_bf16
-    monkeypatch.setattr(B, "gemm_bf16", lambda *a, **k: plain(*a, variant=v, two_barriers=not one_barrier, **k))
+    monkeypatch.setattr(B, "gemm_bf16", lambda *a, **k: plain(*a, variant=v, **k))
     yield v
 
 
@@ -114,10 +113,10 @@ def test_layernorm_bf16_out(oracle):
 
 
 @pytest.mark.parametrize("mfma", [1, 0, 2], ids=["bf16-mfma", "fp32-mfma", "bf16-mfma-qscaled"])
-@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (1, 50, 2), (1, 224, 1), (1, 33, 1), (1, 577, 2), (2, 300, 1), (1, 225, 1)])
+@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (1, 50, 2), (1, 224, 1), (1, 33, 1), (1, 577, 2), (2, 300, 1), (1, 225, 1), (1, 740, 2)])
 def test_attention_bf16_io(oracle, n, T, heads, mfma):
     """bf16 Q/K/V in, bf16 out.  mfma=1: both products on bf16 MFMA, P rounded to bf16 (resident kernel up to
-    224 tokens, streamed online-softmax kernel beyond); mfma=0: fp32 MFMA on the widened values; mfma=2: as 1 with the Q columns
+    224 tokens, streamed online-softmax kernel up to 704, chunked kernel beyond); mfma=0: fp32 MFMA on the widened values; mfma=2: as 1 with the Q columns
     holding QSCALE * q (what the engine's folded in_proj writes): the streamed kernel then starts its score accumulators at -max."""
     D = heads * 64
     vals = u(13, (n * T, 3 * D), 1.5)
@@ -187,6 +186,23 @@ def test_bf16_forward_small_models(oracle, cfg, n, ln_fold):
     eng = B.Engine(cfg, max_batch=4, dtype="bf16", ln_fold=ln_fold)
     eng.load_weights(W)
     imgs = synth.make_images(cfg, n, 100)
+    probs = eng.forward(imgs)
+    ref = oracle.forward(oracle_config(cfg), imgs, W)
+    assert float(np.abs(probs - ref).max()) <= BF16_PROB_TOL
+    assert (probs.argmax(1) == ref.argmax(1)).all()
+    eng.close()
+
+
+def test_bf16_forward_beyond_704_tokens(oracle, ln_fold):
+    """730 tokens: past the streamed attention kernel's range, so the chunked kernel runs -- with the LayerNorm fold on it receives
+    Q columns that already hold QSCALE * q (the in_proj fold) and must not scale them again."""
+    from conftest import oracle_config
+    cfg = synth.ModelConfig(img_size=432, patch_size=16, in_chans=3, num_classes=10, embed_dim=128, depth=2, num_heads=2, hidden_dim=256)
+    assert cfg.tokens == 730
+    W = synth.make_weights(cfg, 23)
+    eng = B.Engine(cfg, max_batch=2, dtype="bf16", ln_fold=ln_fold)
+    eng.load_weights(W)
+    imgs = synth.make_images(cfg, 3, 101)
     probs = eng.forward(imgs)
     ref = oracle.forward(oracle_config(cfg), imgs, W)
     assert float(np.abs(probs - ref).max()) <= BF16_PROB_TOL
@@ -265,13 +281,12 @@ def test_ln_fold_is_invariant_to_lanes_chunks_and_pruning():
     imgs = synth.make_images(cfg, 11, 78)
     outs = {}
     for key, kw in {"base": dict(max_batch=16), "lanes3": dict(max_batch=16, lanes=3), "chunks": dict(max_batch=4, lanes=2),
-                    "split": dict(max_batch=16, lanes=2, lane_split=1),   # each lane's persistent launches on half of the CUs
                     "pruned": dict(max_batch=16, prune_last_layer=True), "kernels": dict(max_batch=16, ln_fold=-1)}.items():
         eng = B.Engine(cfg, dtype="bf16", **kw)
         eng.load_weights(W)
         outs[key] = eng.forward(imgs)
         eng.close()
-    for same in ("lanes3", "chunks", "split", "pruned"):
+    for same in ("lanes3", "chunks", "pruned"):
         assert np.array_equal(outs[same], outs["base"]), same
     assert np.array_equal(outs["base"][::-1], B_forward_reversed(cfg, W, imgs))
     d = float(np.abs(outs["kernels"] - outs["base"]).max())

@@ -41,6 +41,7 @@ def test_product_library_has_no_probe_entry_points_or_tuning_setters():
     names = {ln.split()[-1] for ln in syms.splitlines() if ln.strip()}
     banned = [n for n in names if n.startswith("vithip_probe_") or n.endswith("_set_debug_buffer") or
               re.fullmatch(r"vithip_\w+_set_(tile|group|variant|sync|stagger|max_workgroups|mfma)", n)]
+    assert "vithip_gemm_f32" in names and "vithip_gemm_bf16" in names
     assert not banned, banned
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "vision-transformer-opencl_amd", "csrc", "vit_probes.h")).read(), flags=re.S)
     probe_decl = set(re.findall(r"^int (\w+)\(", text, flags=re.M))

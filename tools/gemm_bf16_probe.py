@@ -11,31 +11,6 @@ L.vithip_gemm_bf16.argtypes = [C.c_void_p, C.POINTER(B.CGemmBf16Args)]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 M = batch * 197
 SHAPES = {"qkv": (M, 2304, 768, 0), "outproj": (M, 768, 768, 2), "fc1": (M, 3072, 768, 1), "fc2": (M, 768, 3072, 2)}
-if len(sys.argv) > 2 and sys.argv[2] in ("stagger", "sync"):
-    for st in ((0, 1, 0, 1) if sys.argv[2] == "sync" else (0, 1, 2, 3, 4, 6)):
-        if sys.argv[2] == "sync":
-            L.vithip_gemm_bf16_set_sync(st)
-        else:
-            L.vithip_gemm_bf16_set_stagger(st)
-        L.vithip_gemm_bf16_set_variant(2)
-        out = {}
-        for name, (M_, N, K, epi) in SHAPES.items():
-            rng = np.random.default_rng(0)
-            a = rng.integers(0x3c00, 0x4000, size=(M_, K), dtype=np.uint16); a[::2] |= 0x8000
-            dA = B.DeviceArray.from_numpy(a)
-            dW = B.DeviceArray.from_numpy(B.to_bf16_bits(rng.uniform(-.05, .05, (N, K)).astype(np.float32)))
-            db = B.DeviceArray.from_numpy(rng.uniform(-.1, .1, (N,)).astype(np.float32))
-            dC = B.DeviceArray((M_, N), np.float32 if epi == 2 else np.uint16)
-            args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi)
-            ms = [timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=3, warm=1) for _ in range(3)]
-            out[name] = round(2.0 * M_ * N * K / (min(ms) * 1e-3) / 1e12, 1)
-            for d in (dA, dW, db, dC):
-                d.free()
-        print(json.dumps({sys.argv[2]: st, "tflops": out}))
-    L.vithip_gemm_bf16_set_stagger(0)
-    L.vithip_gemm_bf16_set_sync(1)
-    L.vithip_gemm_bf16_set_variant(0)
-    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "probe":  # timing-only builds on the qkv shape: 101 = no DMA in loop, 102 = DMA only
     SHAPES = {"qkv": (M, 2304, 768, 0), "pp_no_dma": (M, 2304, 768, 201), "pp_no_mfma": (M, 2304, 768, 202), "pp_no_reads": (M, 2304, 768, 203), "pp_no_epilogue": (M, 2304, 768, 204), "pp_K3072": (M, 2304, 3072, 0), "pp_K3072_no_epi": (M, 2304, 3072, 204),
               "qkv_no_dma": (M, 2304, 768, 101), "qkv_dma_only": (M, 2304, 768, 102)}

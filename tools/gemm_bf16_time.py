@@ -45,7 +45,7 @@ for name, (M_, N, K, epi) in SHAPES.items():
         tail = (extra[0].ptr, extra[1].ptr, None, 0, None)
     else:
         tail = (None, None, None, 0, None)
-    args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi, 0, 0, 0, *tail)
+    args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi, 0, *tail)
     ms = min(timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=5, warm=2) for _ in range(3))
     out[name] = {"ms": round(ms, 4), "tflops": round(2.0 * M_ * N * K / (ms * 1e-3) / 1e12, 1)}
     for d in [dA, dW, db, dC] + extra:

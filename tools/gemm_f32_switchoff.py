@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Where the fp32 persistent GEMM's time goes: the product kernel against timing-only builds with one part switched off
-(csrc/vit_gemm_persistent.hip, -DPG_DBG=n: 1 no epilogue stores, 2 no staging loads in the K loop, 3 no K-loop barrier,
-4 no fragment reads, 5 no staging ds_writes, 6 = 2 + 5; results wrong by construction).  Every library runs in its own process
-(VIT_HIP_LIBRARY), the set is repeated so that drift shows.  GPU box only.
+"""Where the fp32 persistent GEMM's time goes: the product kernel against timing-only instantiations with one part switched off
+(csrc/vit_gemm_persistent.hip, template parameter DBG = n: 1 no epilogue stores, 2 no staging loads in the K loop, 3 no K-loop
+barrier, 4 no fragment reads, 5 no staging ds_writes, 6 = 2 + 5; results wrong by construction).  They exist in the probe library
+only (tile codes 130 + n through vithip_gemm_set_tile).  Every variant runs in its own process, the set is repeated so that drift
+shows.  GPU box only.
 
-    make -C vision-transformer-opencl_amd switchoff        # build/dbg/libvit_pg<n>.so
-    python tools/gemm_f32_switchoff.py [rounds] [more build/dbg/libvit_<name>.so names for an A/B]
+    make -C vision-transformer-opencl_amd probes           # libvit_mi355x_probe.so
+    python tools/gemm_f32_switchoff.py [rounds]
 
 Read the numbers with DESIGN 4.1 item 11 in mind: every such build freezes the MFMAs' operand data, and the fp32 GEMM is
 power-limited (tools/gemm_f32_data_power.py) -- most of what a build "saves" is clock, not the instructions it dropped.
@@ -22,6 +23,8 @@ def child():
     B = importlib.import_module("vision-transformer-opencl_amd.binding")
     from tools.gemm_probe import timed
     L = B.lib()
+    dbg = int(os.environ["PG_CHILD"])
+    B.hip_check(L.vithip_gemm_set_tile(130 + dbg if dbg else 9), "vithip_gemm_set_tile")
     rng = np.random.default_rng(0)
     out = {}
     for name, (M, N, K, epi) in SHAPES.items():
@@ -39,21 +42,16 @@ def child():
 
 
 if __name__ == "__main__":
-    if os.environ.get("PG_CHILD"):
+    if os.environ.get("PG_CHILD") is not None:
         child()
         sys.exit(0)
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    names = {"pg0": "product", "pg1": "no epilogue", "pg2": "no staging loads", "pg3": "no barrier", "pg4": "no fragment reads",
-             "pg5": "no ds_writes", "pg6": "no staging at all"}
-    if len(sys.argv) > 2:
-        names = {}
-    names.update({a: a for a in sys.argv[2:]})   # further A/B libraries: build/dbg/libvit_<name>.so
+    names = {0: "as shipped", 1: "no epilogue", 2: "no staging loads", 3: "no barrier", 4: "no fragment reads",
+             5: "no ds_writes", 6: "no staging at all"}
+    lib = os.path.join(ROOT, "vision-transformer-opencl_amd", "libvit_mi355x_probe.so")
     for r in range(rounds):
         for n, what in names.items():
-            lib = os.path.join(ROOT, "vision-transformer-opencl_amd", "build", "dbg", f"libvit_{n}.so")
-            if not os.path.exists(lib):
-                continue
-            env = dict(os.environ, PG_CHILD="1", VIT_HIP_LIBRARY=lib)
+            env = dict(os.environ, PG_CHILD=str(n), VIT_HIP_LIBRARY=lib)
             res = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=300)
             line = res.stdout.strip().splitlines()[-1] if res.stdout.strip() else res.stderr[-300:]
             print(json.dumps({"round": r, "build": what, "ms": json.loads(line) if line.startswith("{") else line}), flush=True)

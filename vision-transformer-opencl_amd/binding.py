@@ -49,7 +49,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
                 ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int), ("ln_fold", C.c_int),
-                ("gemm_handover_test", C.c_int), ("lane_split", C.c_int)]
+                ("gemm_handover_test", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -258,13 +258,24 @@ def gemm_workspace_flags(ws: int, count: int = 1016) -> np.ndarray:
     return flags
 
 
+def gemm_workspace_set_flags(ws: int, values) -> None:
+    """Overwrite the first len(values) per-owner flags (tests: what an aborted launch may have left behind)."""
+    L = lib()
+    L.vithip_gemm_f32_workspace_device_ptr.restype = C.c_void_p
+    L.vithip_gemm_f32_workspace_device_ptr.argtypes = [C.c_void_p]
+    v = np.ascontiguousarray(values, np.int32)
+    hip_check(L.vithip_device_sync(), "sync")
+    hip_check(L.vithip_memcpy_h2d(L.vithip_gemm_f32_workspace_device_ptr(ws), v.ctypes.data, v.nbytes, None), "h2d")
+    hip_check(L.vithip_device_sync(), "sync")
+
+
 class CGemmBf16Args(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int), ("bias", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
-                ("variant", C.c_int), ("two_barriers", C.c_int), ("stagger", C.c_int),
+                ("variant", C.c_int),
                 ("ln_rows", C.c_void_p), ("ln_colsum", C.c_void_p), ("x16", C.c_void_p), ("ldx16", C.c_int),
-                ("row_partials", C.c_void_p), ("max_workgroups", C.c_int)]
+                ("row_partials", C.c_void_p)]
 
 
 BF16_EPI_BF16, BF16_EPI_BF16_GELU, BF16_EPI_F32_RESIDUAL = 0, 1, 2
@@ -291,10 +302,10 @@ def f32_to_bf16_device(x: np.ndarray) -> np.ndarray:
     return dy.numpy()
 
 
-def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16, variant: int = 0, two_barriers: bool = False,
-              stagger: int = 0, ln_rows=None, ln_colsum=None, ln_producer: bool = False):
+def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16, variant: int = 0, ln_rows=None, ln_colsum=None,
+              ln_producer: bool = False):
     """vithip_gemm_bf16 on bf16 bit patterns; returns bf16 bits (uint16) or fp32 for the residual epilogue.
-    variant: 0 auto, 1 two-stage kernel, 2 ping-pong kernel (fails for K < 128); two_barriers: its other barrier schedule.
+    variant: 0 auto, 1 two-stage kernel, 2 ping-pong kernel (fails for K < 128).
     LayerNorm fold: ln_rows [M][2] + ln_colsum [N] make this the consumer; ln_producer (residual epilogue) also returns
     (C, bf16(C) bits, row partials [strips][M][2])."""
     L = lib()
@@ -312,7 +323,7 @@ def gemm_bf16(A_bits, W_bits, bias, residual=None, epilogue=BF16_EPI_BF16, varia
     dX16 = DeviceArray((M, N), np.uint16) if ln_producer else None
     dPart = DeviceArray((strips, M, 2), np.float32) if ln_producer else None
     args = CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue,
-                         variant, 1 if two_barriers else 0, stagger, dRows.ptr if dRows else None, dCs.ptr if dCs else None,
+                         variant, dRows.ptr if dRows else None, dCs.ptr if dCs else None,
                          dX16.ptr if dX16 else None, N, dPart.ptr if dPart else None)
     hip_check(L.vithip_gemm_bf16(None, C.byref(args)), "vithip_gemm_bf16")
     if ln_producer:
@@ -384,8 +395,8 @@ def attention_bf16io(qkv_bits, n_images: int, tokens: int, heads: int, f32math: 
     do = DeviceArray((n_images * tokens, D), np.uint16)
     if q_scaled:
         fn = lib().vithip_attention_bf16io_qscaled
-        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-        hip_check(fn(None, dq.ptr, do.ptr, n_images, tokens, heads, q_rows or tokens, 0), "vithip_attention_bf16io_qscaled")
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        hip_check(fn(None, dq.ptr, do.ptr, n_images, tokens, heads, q_rows or tokens), "vithip_attention_bf16io_qscaled")
         return do.numpy()
     fn = getattr(lib(), "vithip_attention_bf16io_f32math" if f32math else "vithip_attention_bf16io")
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -487,12 +498,12 @@ class Engine:
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
                  lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False,
-                 gemm_tile: int = 0, ln_fold: int = 0, gemm_handover_test: int = 0, lane_split: int = 0):
+                 gemm_tile: int = 0, ln_fold: int = 0, gemm_handover_test: int = 0):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
         opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
-                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold, gemm_handover_test, lane_split)
+                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold, gemm_handover_test)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

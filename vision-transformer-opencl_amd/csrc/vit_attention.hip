@@ -32,7 +32,7 @@ extern unsigned long long *g_stream_dbg;
 extern int g_res_mode;
 #endif
 int attention_f32_resident(hipStream_t s, const float *qkv, float *out, int n_images, int tokens, int heads, int q_rows);  // vit_attention_resident.hip
-int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads, bool q_scaled, int max_wgs);  // vit_attention_stream.hip
+int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads, bool q_scaled);  // vit_attention_stream.hip
 }
 
 namespace {
@@ -622,7 +622,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
 // chunks of 224 keys with the online softmax of attention_f32_chunked_kernel.  ViT-L/16-384 (577 tokens).
 __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(const bf16_t *__restrict__ qkv,
                                                                              bf16_t *__restrict__ out, int tokens,
-                                                                             int heads) {
+                                                                             int heads, float kScale) {
+    // kScale: (1/sqrtf(64)) * log2(e) for plain q, 1 when the Q columns already hold that multiple of q (as in attention_bf16_kernel)
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * CKEYS * HD];
     bf16_t *const Ks = lds;
     bf16_t *const Vs = lds + CKEYS * HD;
@@ -650,7 +651,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(con
 #pragma unroll
         for (int v = 0; v < 16; ++v) o[dt][v] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
-    constexpr float kScale = 0.125f * 1.4426950408889634f;
     const int h4 = 4 * h, sw = (r >> 1) & 7;
 
     // the K/V rows of chunk ch+1 are fetched into registers while chunk ch is multiplied (one workgroup per CU fits,
@@ -774,13 +774,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_chunked_kernel(con
 }
 
 template <int NKT>
-int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads, int q_rows, bool q_scaled, int max_wgs) {
+int launch_bf16(hipStream_t s, const bf16_t *qkv, bf16_t *out, int n_images, int tokens, int heads, int q_rows, bool q_scaled) {
     const int items = heads * n_images;
     const int cus = vitdev::current_cus();
     if (cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     const int per_cu = NKT <= 3 ? 2 : 1;  // VGPR-limited residency (8 waves per workgroup)
-    int grid = items < cus * per_cu ? items : cus * per_cu;
-    if (max_wgs > 0 && max_wgs < grid) grid = max_wgs;
+    const int grid = items < cus * per_cu ? items : cus * per_cu;
     hipLaunchKernelGGL(attention_bf16_kernel<NKT>, dim3(grid), dim3(ATT_THREADS), 0, s, qkv, out, tokens, heads, items, q_rows,
                        q_scaled ? 1.0f : 0.125f * 1.4426950408889634f);
     return static_cast<int>(hipGetLastError());
@@ -845,15 +844,15 @@ extern "C" int vithip_attention_f32(vithip_stream_t stream, const float *qkv, fl
 // bf16 variant: qkv and out hold bf16 bits; K/V are widened to fp32 while staged into LDS and all
 // arithmetic (fp32 MFMA, softmax) is the same as above; the output is rounded to bf16 once.
 static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images, int tokens,
-                              int heads, int q_rows, bool bf16_mfma = true, bool q_scaled = false, int max_wgs = 0);
+                              int heads, int q_rows, bool bf16_mfma = true, bool q_scaled = false);
 
 // As vithip_attention_bf16io / _rows, for Q columns that already hold 0.125 * log2(e) * q (the factor of the scores' exponent,
 // folded into the in_proj weights by the engine: q is then rounded to bf16 once, as before, and the kernels save the scaling).
 // q_rows < tokens needs tokens <= 224.
 extern "C" int vithip_attention_bf16io_qscaled(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
-                                               int n_images, int tokens, int heads, int q_rows, int max_workgroups) {
-    if ((q_rows != tokens && tokens > 224) || max_workgroups < 0) return static_cast<int>(hipErrorInvalidValue);
-    return attention_bf16io_q(stream, qkv, out, n_images, tokens, heads, q_rows, true, true, max_workgroups);
+                                               int n_images, int tokens, int heads, int q_rows) {
+    if (q_rows != tokens && tokens > 224) return static_cast<int>(hipErrorInvalidValue);
+    return attention_bf16io_q(stream, qkv, out, n_images, tokens, heads, q_rows, true, true);
 }
 
 extern "C" int vithip_attention_bf16io(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out,
@@ -883,7 +882,7 @@ extern "C" int vithip_attention_bf16io_rows(vithip_stream_t stream, const unsign
 }
 
 static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv, unsigned short *out, int n_images, int tokens,
-                              int heads, int q_rows, bool bf16_mfma, bool q_scaled, int max_wgs) {
+                              int heads, int q_rows, bool bf16_mfma, bool q_scaled) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (q_rows <= 0 || q_rows > tokens) return static_cast<int>(hipErrorInvalidValue);
     if (!qkv || !out || n_images <= 0 || tokens <= 0 || heads <= 0 || (reinterpret_cast<size_t>(qkv) & 15) ||
@@ -891,21 +890,20 @@ static int attention_bf16io_q(vithip_stream_t stream, const unsigned short *qkv,
         return static_cast<int>(hipErrorInvalidValue);
     if (bf16_mfma) {  // bf16 matrix path while K/V of a head fit LDS; longer sequences use the chunked kernel
         switch ((tokens + 31) / 32) {
-            case 1: return launch_bf16<1>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled, max_wgs);
-            case 2: return launch_bf16<2>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled, max_wgs);
-            case 3: return launch_bf16<3>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled, max_wgs);
-            case 4: return launch_bf16<4>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled, max_wgs);
-            case 5: return launch_bf16<5>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled, max_wgs);
-            case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled, max_wgs);
-            case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled, max_wgs);
+            case 1: return launch_bf16<1>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled);
+            case 2: return launch_bf16<2>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled);
+            case 3: return launch_bf16<3>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled);
+            case 4: return launch_bf16<4>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled);
+            case 5: return launch_bf16<5>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled);
+            case 6: return launch_bf16<6>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled);
+            case 7: return launch_bf16<7>(s, qkv, out, n_images, tokens, heads, q_rows, q_scaled);
             default: {
                 // 225..704 tokens (ViT-L/16-384: 577): all query blocks of a head in one persistent workgroup, K/V streamed
                 // once through an LDS-DMA ring (vit_attention_stream.hip); longer sequences: the chunked kernel below
-                if (tokens <= 704) return vitattn::attention_bf16_stream(s, qkv, out, n_images, tokens, heads, q_scaled, max_wgs);
-                if (q_scaled) return static_cast<int>(hipErrorInvalidValue);  // the chunked kernel for > 704 tokens takes plain q
+                if (tokens <= 704) return vitattn::attention_bf16_stream(s, qkv, out, n_images, tokens, heads, q_scaled);
                 const int qblocks = ((tokens + 31) / 32 + ATT_WAVES - 1) / ATT_WAVES;
                 hipLaunchKernelGGL(attention_bf16_chunked_kernel, dim3(heads, n_images, qblocks), dim3(ATT_THREADS), 0, s, qkv,
-                                   out, tokens, heads);
+                                   out, tokens, heads, q_scaled ? 1.0f : 0.125f * 1.4426950408889634f);
                 return static_cast<int>(hipGetLastError());
             }
         }

@@ -486,7 +486,7 @@ static int launch_stream(hipStream_t s, const unsigned short *qkv, unsigned shor
     return static_cast<int>(hipGetLastError());
 }
 
-int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads, bool q_scaled, int max_wgs) {
+int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned short *out, int n_images, int tokens, int heads, bool q_scaled) {
     int dev = 0;
     const int cus = vitdev::current_cus(&dev);
     if (cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
@@ -494,8 +494,7 @@ int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned sho
     const size_t lds_bytes = (size_t)(2 * SBUF + nblk * 32 * SHD) * sizeof(bf16_t);  // ring + the head's Q blocks
     if (tokens > ST_WAVES * MAXB * 32 || lds_bytes > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     const int items = n_images * heads;
-    int grid = items < cus ? items : cus;
-    if (max_wgs > 0 && max_wgs < grid) grid = max_wgs;
+    const int grid = items < cus ? items : cus;
     return q_scaled ? launch_stream<true>(s, qkv, out, tokens, heads, items, grid, lds_bytes, dev)
                     : launch_stream<false>(s, qkv, out, tokens, heads, items, grid, lds_bytes, dev);
 }

@@ -37,6 +37,7 @@
 namespace vitgemm {
 int launch_persistent(hipStream_t stream, GemmParams &p, int epilogue, int group_m);  // vit_gemm_persistent.hip
 int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, int group_m);
+int launch_persistent_switchoff(hipStream_t stream, GemmParams &p, int epilogue, int group_m, int dbg);  // probe build
 int persistent_piece_steps(int M, int N, int K, int slots, int wgs);
 }
 
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
             if constexpr (AMODE == A_DENSE) return k0 * 4;
             const int pp2 = p.patch * p.patch;
             const int ic = k0 / pp2, kh = (k0 - ic * pp2) / p.patch;  // wave-uniform: scalar divisions, once per K step
-            return ((ic * p.img + kh) * p.img) * 4;
+            // + the K step's start inside the pixel row: 0 for patch <= 32, 32 / 64 / ... floats for patch 64, 96, ... (whose rows span
+            // several K steps; the thread's own ld_kc % patch is in a_boff)
+            return ((ic * p.img + kh) * p.img + (k0 - ic * pp2 - kh * p.patch)) * 4;
         };
         auto load_global_pipe = [&](int k0) {
             const int ka = a_koff(k0);
@@ -385,32 +388,32 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
             case 129: p.dbg = g_gemm_dbg; return g_gemm_dbg ? vitgemm::launch_persistent_stamped(stream, p, epilogue, p.group_m) : static_cast<int>(hipErrorInvalidValue);
             case 125: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5, VITHIP_EPI_BIAS, true>(stream, p) : static_cast<int>(hipErrorInvalidValue);
             case 126: p.dbg = g_gemm_dbg; return g_gemm_dbg ? launch_probe<5, VITHIP_EPI_BIAS_GELU, true>(stream, p) : static_cast<int>(hipErrorInvalidValue);
+            case 131: case 132: case 133: case 134: case 135: case 136:  // persistent walk with one part switched off
+                return vitgemm::launch_persistent_switchoff(stream, p, epilogue, p.group_m, tile - 130);
             default: break;
         }
     }
 #endif
     if constexpr (AMODE == A_PATCHES) {
         // 0.7 % of the FLOPs (the gather indices and the token-row remap of the fused epilogue cost ~40 VGPRs on top of the dense
-        // kernel).  tile 1 / 2: 128x128 / 256x128 (probe override); default 128x64
+        // kernel): 128x64 tiles
         // pipelined loop when a K step of 32 is a whole number of pixel rows or a part of one (patch 8, 16, 32, ...) and the images
-        // are addressable by 32-bit byte offsets; the classic loop (tile 3) otherwise
+        // are addressable by 32-bit byte offsets; the classic (not software-pipelined) loop otherwise
         const bool pipe_ok = (32 % p.patch == 0 || p.patch % 32 == 0) && (p.patch * p.patch) % 32 == 0 &&
                              (size_t)(p.M / p.patches + 1) * p.chans * p.img * p.img * 4 < 0x7fffffffull;
+#ifdef VIT_PROBES  // tools/embed_f32_time.py: other tile shapes of the gather
         if (tile == 1) return launch_tile<128, 128, 64, 64, A_PATCHES>(stream, p, epilogue);
         if (tile == 2) return launch_tile<256, 128, 128, 64, A_PATCHES>(stream, p, epilogue);
-        if (tile == 3 || !pipe_ok) return launch_tile<128, 64, 64, 32, A_PATCHES>(stream, p, epilogue);
+        if (tile == 10) return launch_tile<128, 128, 64, 64, A_PATCHES, 32, true>(stream, p, epilogue);
+        if (tile == 3) return launch_tile<128, 64, 64, 32, A_PATCHES>(stream, p, epilogue);
+#endif
+        if (!pipe_ok) return launch_tile<128, 64, 64, 32, A_PATCHES>(stream, p, epilogue);
         // measured at batch 256 (tools/embed_f32_time.py, two interleaved rounds): classic 128x64 0.556 ms, pipelined 128x128
         // 0.504-0.556, pipelined 128x64 0.499-0.531 = 118 TFLOP/s (0.75 of the fp32 matrix peak): every 64-wide N tile re-reads its
         // pixels through the L2s, 12 x 154 MB per launch
-        if (tile == 10) return launch_tile<128, 128, 64, 64, A_PATCHES, 32, true>(stream, p, epilogue);
         return launch_tile<128, 64, 64, 32, A_PATCHES, 32, true>(stream, p, epilogue);
     }
     switch (tile) {
-        case 2: return launch_tile<256, 128, 128, 64, AMODE>(stream, p, epilogue);
-        case 3: return launch_tile<128, 64, 64, 32, AMODE>(stream, p, epilogue);
-        case 4: return launch_tile<128, 128, 64, 64, AMODE, 16>(stream, p, epilogue);
-        case 5: return launch_tile<128, 64, 64, 32, AMODE, 16>(stream, p, epilogue);
-        case 1: return launch_tile<128, 128, 64, 64, AMODE>(stream, p, epilogue);       // classic K loop
         case 9: return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);   // persistent, cross-tile pipelined
         case 6: return launch_tile<128, 128, 64, 64, AMODE, 16, true>(stream, p, epilogue);
         case 7: return launch_tile<256, 128, 128, 64, AMODE, 32, true>(stream, p, epilogue);
@@ -462,7 +465,7 @@ extern "C" {
 #ifdef VIT_PROBES
 // Probe build only: process-wide overrides of the per-call tile / group fields (0 = none).
 int vithip_gemm_set_tile(int tile) {
-    if ((tile < 0 || tile > 10) && (tile < 101 || tile > 129)) return static_cast<int>(hipErrorInvalidValue);
+    if ((tile < 0 || tile > 12) && (tile < 101 || tile > 136)) return static_cast<int>(hipErrorInvalidValue);
     g_gemm_tile = tile;
     return 0;
 }
@@ -489,6 +492,7 @@ struct GemmWorkspace {
     void *dev;
     int slots;
     int device;
+    int gen;  // launches that used it so far: every launch tags its flag words with its number (vit_gemm_persistent.hip)
 };
 static size_t workspace_dev_bytes(int slots) { return 4096 + (size_t)slots * 128 * 128 * 4; }
 
@@ -505,7 +509,7 @@ int vithip_gemm_f32_workspace_create(void **ws) {
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return static_cast<int>(e);
-    GemmWorkspace *w = new (std::nothrow) GemmWorkspace{nullptr, 2 * cus, dev};
+    GemmWorkspace *w = new (std::nothrow) GemmWorkspace{nullptr, 2 * cus, dev, 0};
     if (!w) return static_cast<int>(hipErrorOutOfMemory);
     e = hipExtMallocWithFlags(&w->dev, workspace_dev_bytes(w->slots), hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(w->dev, 0, 4096);
@@ -560,15 +564,17 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldc = a->ldc;
     p.M = a->M; p.N = a->N; p.K = a->K;
     if (a->workspace) {
-        const GemmWorkspace *w = static_cast<const GemmWorkspace *>(a->workspace);
+        GemmWorkspace *w = static_cast<GemmWorkspace *>(a->workspace);
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess || dev != w->device) return static_cast<int>(hipErrorInvalidDevice);  // made on another device
         p.sk_ws = w->dev;
         p.sk_slots = w->slots;
         p.sk_late = a->handover_test == 1;
+        w->gen = w->gen >= (1 << 28) ? 1 : w->gen + 1;  // (launches on one workspace are ordered by contract: one stream, one caller)
+        p.sk_gen = w->gen;
     }
     if (a->handover_test < 0 || a->handover_test > 1) return static_cast<int>(hipErrorInvalidValue);
-    if (a->tile < 0 || a->tile > 12 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
+    if (a->tile < 0 || (a->tile > 0 && a->tile < 6) || a->tile > 12 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
     return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue, a->tile, a->group_m);
 }
 

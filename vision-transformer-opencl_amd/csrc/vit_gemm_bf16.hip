@@ -302,14 +302,11 @@ __global__ void cls_rows_bf16path_kernel(const float *cls, const float *pos, flo
 }
 
 bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
-// Kernel variant, barrier schedule and start-up skew are per-call fields of vithip_gemm_bf16_args; the product library
-// has no mutable process-wide state.  The probe build (-DVIT_PROBES) adds process-wide overrides and instrumented kernels.
+// The kernel variant is a per-call field of vithip_gemm_bf16_args; the product library has no mutable process-wide state.  The probe build (-DVIT_PROBES) adds process-wide overrides and instrumented kernels.
 #ifdef VIT_PROBES
 int g_variant = 0;  // 0 none, 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong, 4 event-log ping-pong
 unsigned long long *g_dbg = nullptr;
-int g_stagger = -1;   // -1 = no override
-int g_sync1 = -1;     // -1 = no override
-int g_max_wgs = 0;    // cap on persistent workgroups (0 = one per CU)
+int g_max_wgs = 0;    // event-log build: cap on persistent workgroups (0 = one per CU)
 #endif
 
 }  // namespace
@@ -331,17 +328,6 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
 int vithip_gemm_bf16_set_variant(int variant) {
     if (variant < 0 || variant > 4) return static_cast<int>(hipErrorInvalidValue);
     g_variant = variant;
-    return 0;
-}
-
-int vithip_gemm_bf16_set_sync(int one_barrier) {
-    g_sync1 = one_barrier < 0 ? -1 : (one_barrier != 0);
-    return 0;
-}
-
-int vithip_gemm_bf16_set_stagger(int units) {
-    if (units < -1 || units > 64) return static_cast<int>(hipErrorInvalidValue);
-    g_stagger = units;
     return 0;
 }
 
@@ -384,8 +370,6 @@ int vithip_patch_embed_bf16(vithip_stream_t stream, const float *images, const u
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
     p.patches = P;
-    p.stagger = 0;
-    p.sync1 = 1;
     const int g_cus = vitdev::current_cus();  // of the current device, asked per call (engines of several devices share the process)
     if (g_cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     return vitgemm::launch_gemm_bf16_pp(s, p, VITHIP_BF16_EPI_F32_EMBED, g_cus);
@@ -422,7 +406,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     p.tiles_m = (p.M + TBM - 1) / TBM;
     p.tiles_n = (p.N + TBN - 1) / TBN;
     p.group_m = 8;
-    if (a->variant < 0 || a->variant > 2 || a->stagger < 0 || a->stagger > 64) return static_cast<int>(hipErrorInvalidValue);
+    if (a->variant < 0 || a->variant > 2) return static_cast<int>(hipErrorInvalidValue);
     // LayerNorm fold: consumer (ln_rows + ln_colsum on the bf16 epilogues) or producer (x16 + row_partials on the residual one)
     const bool ln_consumer = a->ln_rows || a->ln_colsum, ln_producer = a->x16 || a->row_partials;
     if (ln_consumer) {
@@ -440,13 +424,9 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
         p.ldx16 = a->ldx16;
         p.partials = a->row_partials;
     }
-    p.stagger = a->stagger;
-    p.sync1 = a->two_barriers ? 0 : 1;
     int variant = a->variant;
 #ifdef VIT_PROBES
     if (g_variant) variant = g_variant;
-    if (g_stagger >= 0) p.stagger = g_stagger;
-    if (g_sync1 >= 0) p.sync1 = g_sync1;
 #endif
     const int g_cus = vitdev::current_cus();  // of the current device, asked per call (engines of several devices share the process)
     if (g_cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
@@ -473,9 +453,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
         return vitgemm::launch_gemm_bf16_pp(s, p, 300 + a->epilogue, g_max_wgs ? g_max_wgs : g_cus);
     }
 #endif
-    if (a->max_workgroups < 0) return static_cast<int>(hipErrorInvalidValue);
-    if (variant != 1 && pp_ok)
-        return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, a->max_workgroups > 0 && a->max_workgroups < g_cus ? a->max_workgroups : g_cus);
+    if (variant != 1 && pp_ok) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);
     switch (a->epilogue) {
 #ifdef VIT_PROBES
         case 101: hipLaunchKernelGGL((gemm_bf16_nt_kernel<VITHIP_BF16_EPI_BF16, 1>), grid, block, 0, s, p); break;

@@ -68,21 +68,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 
 // STAMP: timing-only instrumentation for tools/gemm_bf16_probe.py (workgroup 0 records s_memtime around the
 // sections of K step 3 of its first tile, and around that tile's epilogue; 32 values per wave in p.dbg).
-// Barriers of the phase pipeline.  Two schedules (Bf16Params::sync1):
-//   sync1 = 0: every phase has a barrier after its load section AND after its MFMA section for all waves; group 1
-//              starts one barrier late, so the groups strictly alternate load / MFMA sections.
-//   sync1 = 1: ONE barrier per phase and wave: group 0 after its MFMA sections, group 1 after its load sections.  Between
-//              two barriers group 0 runs [load p, MFMA p] and group 1 [MFMA p-1, load p]: the same pairing of sections,
-//              but nothing forces them to switch at the same moment, and half the barriers.  Every half-tile is still
-//              waited for (counted vmcnt) before a barrier that precedes its first read, and refilled two phases after
-//              its last read, so the LDS-DMA hazards are covered exactly as before.
-#define PP_BARRIER_L()                  \
-    do {                                \
-        if (!sync1 || g == 1) PP_BARRIER(); \
+// Barriers of the phase pipeline: ONE per phase and wave -- group 0 after its MFMA sections, group 1 after its load sections.
+// Between two barriers group 0 runs [load p, MFMA p] and group 1 [MFMA p-1, load p]: while one group is in its MFMA section the
+// other is in its load section, but nothing forces them to switch at the same moment.  Every half-tile is waited for (counted
+// vmcnt) before a barrier that precedes its first read, and refilled two phases after its last read.  (A schedule with a
+// barrier after every section of every wave -- twice as many -- was 1-3.5 % slower and is gone; so is a start-up skew between
+// the persistent workgroups, which never measured outside the noise.)
+#define PP_BARRIER_L()          \
+    do {                        \
+        if (g == 1) PP_BARRIER(); \
     } while (0)
-#define PP_BARRIER_M()                  \
-    do {                                \
-        if (!sync1 || g == 0) PP_BARRIER(); \
+#define PP_BARRIER_M()          \
+    do {                        \
+        if (g == 0) PP_BARRIER(); \
     } while (0)
 #define PP_MFMA(a, b, c, x, y, z) (DBG == 2 ? (c) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z))
 #define PP_LDS_FRAG(ptr) (DBG == 3 ? bf16x8{} : *reinterpret_cast<const bf16x8 *>(ptr))
@@ -145,11 +143,6 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     const int first = xcd_remap(blockIdx.x, nwg);
     if (first >= total) return;  // workgroup-uniform
     const int nk = p.K / PBK;
-    const bool sync1 = p.sync1 != 0;
-    // Identical persistent workgroups started together stay in lock-step: all 256 epilogues (32 MB of stores)
-    // hit the L2s at the same moment and every workgroup then waits for its stores to drain (vmcnt is in-order).
-    // A start-up skew of p.stagger x 512 cycles per position inside the XCD spreads them over the tile period.
-    for (int i = (blockIdx.x >> 3) * p.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(8);
 
     // ---- LDS-DMA source offsets: per half-tile two instructions (q) of 8 rows x 128 B.  Lane l lands at
     // (row L = 16*wave + 8q + l/8, chunk l%8) of the slot and fetches source chunk (l%8) ^ ((L>>1)&7).
@@ -644,7 +637,6 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     issue(K1{}, 1);
     wait_loads();  // kinds 0 and 1 of K step 0 have landed (four younger half-tiles may be in flight)
     PP_BARRIER();  // everybody: half-tiles 0 and 1 are visible
-    if (!sync1 && g == 1) PP_BARRIER();  // two-barrier schedule: group 1 runs one barrier behind group 0 from here on
 
     if constexpr (STAMP == 1) stamps[20] = (unsigned)__builtin_amdgcn_s_memtime();
     in_loop = true;
@@ -830,10 +822,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         c_tile += nwg;
         if (c_tile >= total) break;
     }
-    if (g == 0) {
-        epilogue(prev_tile, prev_tpar);  // group 0's last tile
-        if (!sync1) PP_BARRIER();        // two-barrier schedule: pairs with group 1's last barrier
-    }
+    if (g == 0) epilogue(prev_tile, prev_tpar);  // group 0's last tile
     if constexpr (STAMP == 1) {
         stamps[23] = (unsigned)__builtin_amdgcn_s_memtime();
         if (blockIdx.x == 0 && lane == 0)

@@ -40,6 +40,7 @@ struct GemmParams {
     int sk_slots;
     int sk_x;
     int sk_late;     // tests: helpers run their pieces last (vithip_gemm_args.handover_test)
+    int sk_gen;      // launch number on this workspace (1 .. 2^28): flag words of other generations read as empty
 };
 
 // erf(x) = sign(x) * (1 - exp(t*q(t))), t = min(|x|, 4), q = degree-7 minimax fit of log(erfc(t))/t
@@ -269,8 +270,6 @@ struct Bf16Params {
     int tiles_m, tiles_n, group_m;
     unsigned long long *dbg;  // stamped probe build only
     int patches;              // F32_EMBED epilogue: patches per image
-    int sync1;                // ping-pong kernel: 1 = one barrier per phase and wave (see PP_BARRIER_L/M)
-    int stagger;              // ping-pong kernel: start-up skew between workgroups, in units of 512 cycles
     // LayerNorm folded into the GEMMs either side of it (ping-pong kernel only; vithip_gemm_bf16_args has the contract):
     const float *ln_rows;     // consumer (BF16 / BF16_GELU): [M][2] = (rstd, mean * rstd) of every row of A
     const float *ln_colsum;   // consumer: [N] column sums of the gamma-folded weight

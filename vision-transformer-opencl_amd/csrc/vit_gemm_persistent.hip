@@ -35,12 +35,6 @@
 // workspace (vithip_gemm_f32_workspace_stats): a recomputed piece costs x K-steps of one workgroup, never a wrong bit.
 #include "vit_gemm_common.hpp"
 
-// PG_DBG (timing-only switch-off builds for tools/gemm_f32_switchoff.py, results wrong by construction; 0 in every shipped object):
-// 1 no epilogue stores, 2 no staging loads inside the K loop, 3 no K-loop barrier, 4 no fragment reads, 5 no staging ds_writes, 6 = 2 + 5.
-// (What such builds measure is mostly the POWER of frozen operand data, not the removed instructions: DESIGN 4.1 item 11.)
-#ifndef PG_DBG
-#define PG_DBG 0
-#endif
 namespace vitgemm {
 
 constexpr int PBK = 32;           // K step
@@ -49,7 +43,11 @@ constexpr int PLD = PBK + 4;      // padded LDS row (floats)
 constexpr int SK_HEADER_BYTES = 4096, SK_MAX_OWNERS = 1000, SK_STAT_TAKEN = 1016, SK_STAT_RECOMPUTED = 1017;
 
 // SK: helper pieces compiled in (launches without them use the SK = false instantiation: no segment bookkeeping in its registers)
-template <int BM, int BN, int WM, int WN, int EPI, bool STAMP = false, bool SK = false>
+// DBG: timing-only switch-off instantiations for tools/gemm_f32_switchoff.py, results wrong by construction; instantiated in the
+// probe build only (libvit_mi355x_probe.so, tile codes 131-136), the product library holds DBG = 0 alone: 1 no epilogue stores,
+// 2 no staging loads inside the K loop, 3 no K-loop barrier, 4 no fragment reads, 5 no staging ds_writes, 6 = 2 + 5.
+// (What such builds measure is mostly the POWER of frozen operand data, not the removed instructions: DESIGN 4.1 item 11.)
+template <int BM, int BN, int WM, int WN, int EPI, bool STAMP = false, bool SK = false, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const GemmParams p) {
     constexpr int ROWS_PER_PASS = 256 / (PBK / 4);
     constexpr int WGN = BN / WN;
@@ -146,23 +144,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     };
 
     // ---- the owner's one look at its slot (workgroup-uniform: thread 0 decides, a barrier and an LDS word tell the rest) -----
-    // flag o: 0 empty, 1 piece parked, 2 request withdrawn.  Relaxed agent-scope atomics on an uncached word; what orders the
-    // DATA against the flag is on the helper's side (park()).  Whatever value a broken earlier run may have left, only an
-    // observed 1 makes the owner read the slot, and a 1 is only ever written behind this launch's data.
+    // flag o: (generation << 2) | state, state 1 = piece parked, 2 = request withdrawn; p.sk_gen numbers the launches that use
+    // the workspace, so ONLY a word written by THIS launch means anything: whatever an aborted earlier launch left behind (a
+    // stale "parked" included) reads as empty.  Relaxed agent-scope atomics on an uncached word; what orders the DATA against the
+    // flag is on the helper's side (park()).  A 1 of this generation is only ever written behind this launch's data.
     int *const sk_flags = reinterpret_cast<int *>(p.sk_ws);
+    const int SK_PARKED = (p.sk_gen << 2) | 1, SK_WITHDRAWN = (p.sk_gen << 2) | 2;
     int steps = 0;                               // K-steps of the whole walk (loop trip count; decide() may shorten it)
     auto decide = [&]() {
         if (tid == 0) {
             int *const f = sk_flags + first;
             int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v != 1) {
-                int expected = 0;
-                v = __hip_atomic_compare_exchange_strong(f, &expected, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 2 : expected;
+            while (v != SK_PARKED) {  // not there: withdraw (whatever stale word is in the way); the helper may park in between
+                int expected = v;
+                if (__hip_atomic_compare_exchange_strong(f, &expected, SK_WITHDRAWN, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    v = SK_WITHDRAWN;
+                    break;
+                }
+                v = expected;
             }
             // taken: the slot is free again as soon as this KERNEL ends (its next writer is a later launch on this stream)
-            if (v == 1) __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(sk_flags + (v == 1 ? SK_STAT_TAKEN : SK_STAT_RECOMPUTED), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sk_decision = v == 1;
+            if (v == SK_PARKED) __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sk_flags + (v == SK_PARKED ? SK_STAT_TAKEN : SK_STAT_RECOMPUTED), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_decision = v == SK_PARKED;
         }
         __syncthreads();
         took = __builtin_amdgcn_readfirstlane(sk_decision) != 0;
@@ -213,13 +217,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     auto restage_slot = [&](int q, int buf, int k0) {
         if (q < A_CHUNKS) {
             float *As = As0 + buf * BM * PLD;
-            if (PG_DBG != 5 && PG_DBG != 6) *reinterpret_cast<f32x4 *>(As + (ld_row + q * ROWS_PER_PASS) * PLD + ld_kc) = a_stage[q];
-            if (PG_DBG != 2 && PG_DBG != 6) a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_src[q], k0 * 4, 0));
+            if (DBG != 5 && DBG != 6) *reinterpret_cast<f32x4 *>(As + (ld_row + q * ROWS_PER_PASS) * PLD + ld_kc) = a_stage[q];
+            if (DBG != 2 && DBG != 6) a_stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_src[q], k0 * 4, 0));
         } else {
             const int qb = q - A_CHUNKS;
             float *Bs = Bs0 + buf * BN * PLD;
-            if (PG_DBG != 5 && PG_DBG != 6) *reinterpret_cast<f32x4 *>(Bs + (ld_row + qb * ROWS_PER_PASS) * PLD + ld_kc) = b_stage[qb];
-            if (PG_DBG != 2 && PG_DBG != 6) b_stage[qb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_src[qb], k0 * 4, 0));
+            if (DBG != 5 && DBG != 6) *reinterpret_cast<f32x4 *>(Bs + (ld_row + qb * ROWS_PER_PASS) * PLD + ld_kc) = b_stage[qb];
+            if (DBG != 2 && DBG != 6) b_stage[qb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_src[qb], k0 * 4, 0));
         }
     };
 
@@ -265,9 +269,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            int expected = 0;  // 0 -> 1: parked.  Found 2: the owner has withdrawn and computes the tile itself -> clear the mark
-            if (!__hip_atomic_compare_exchange_strong(sk_flags + o, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                __hip_atomic_store(sk_flags + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // anything but this launch's "withdrawn" -> parked.  Found the owner's withdrawal (it computes the tile itself): clear it
+            int cur = __hip_atomic_load(sk_flags + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                if (cur == SK_WITHDRAWN) {
+                    __hip_atomic_store(sk_flags + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                int expected = cur;
+                if (__hip_atomic_compare_exchange_strong(sk_flags + o, &expected, SK_PARKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                cur = expected;  // only the owner writes besides us, and only once
+            }
         }
     };
     auto unpark = [&](int o) {  // owner, after decide() saw the flag: the piece is its initial accumulators
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     advance_load_cursor();
     __syncthreads();
     read_frags(0, 0, 0);
-    if (PG_DBG == 4) read_frags(0, 1, 1);
+    if (DBG == 4) read_frags(0, 1, 1);
 
     if constexpr (STAMP) st_loop0 = __builtin_amdgcn_s_memtime();
     int cur = 0;
@@ -330,11 +342,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         const int k_ahead = k_l * PBK;  // offset of the step the restage loads fetch (step g + 2)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            if (c + 1 < NC && PG_DBG != 4) read_frags(cur, c + 1, (c + 1) & 1);
+            if (c + 1 < NC && DBG != 4) read_frags(cur, c + 1, (c + 1) & 1);
             if (c == NC - 1) {
                 // every wave has read buffer `cur` and written buffer `cur^1` (chunk 0): swap point.
-                if (PG_DBG != 3) __syncthreads();
-                if (PG_DBG != 4) read_frags(cur ^ 1, 0, NC & 1);  // first fragments of step g + 1 (maybe the next tile)
+                if (DBG != 3) __syncthreads();
+                if (DBG != 4) read_frags(cur ^ 1, 0, NC & 1);  // first fragments of step g + 1 (maybe the next tile)
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
             unsigned long long e0 = 0;
             if constexpr (STAMP) e0 = __builtin_amdgcn_s_memtime();
             if (SK && out_c >= 0) park(out_c);
-            else if (PG_DBG != 1 || p.M < 0) epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h);  // (M < 0: never; keeps the MFMAs alive)
+            else if (DBG != 1 || p.M < 0) epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h);  // (M < 0: never; keeps the MFMAs alive)
             if constexpr (STAMP) st_epi += __builtin_amdgcn_s_memtime() - e0;
             if (++seg_c < nseg) begin_segment(seg_c);
         }
@@ -460,6 +472,38 @@ int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, i
     return static_cast<int>(hipGetLastError());
 }
 
+
+// Switch-off builds (tools/gemm_f32_switchoff.py; tile codes 131-136 of the probe library): the persistent walk without helper
+// pieces and with one part of the kernel removed.  Timing only.
+template <int DBG>
+static int launch_switchoff_dbg(hipStream_t stream, const GemmParams &p, int epilogue, dim3 grid) {
+    switch (epilogue) {
+        case VITHIP_EPI_BIAS: hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, VITHIP_EPI_BIAS, false, false, DBG>), grid, dim3(256), 0, stream, p); break;
+        case VITHIP_EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, VITHIP_EPI_BIAS_GELU, false, false, DBG>), grid, dim3(256), 0, stream, p); break;
+        case VITHIP_EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, VITHIP_EPI_BIAS_RESIDUAL, false, false, DBG>), grid, dim3(256), 0, stream, p); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+int launch_persistent_switchoff(hipStream_t stream, GemmParams &p, int epilogue, int group_m, int dbg) {
+    const int wgs = persistent_wgs();
+    if (wgs <= 0) return static_cast<int>(hipErrorInvalidDevice);
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = (p.N + 127) / 128;
+    p.group_m = group_m;
+    p.sk_x = 0;
+    const int total = p.tiles_m * p.tiles_n;
+    const dim3 grid(total < wgs ? total : wgs);
+    switch (dbg) {
+        case 1: return launch_switchoff_dbg<1>(stream, p, epilogue, grid);
+        case 2: return launch_switchoff_dbg<2>(stream, p, epilogue, grid);
+        case 3: return launch_switchoff_dbg<3>(stream, p, epilogue, grid);
+        case 4: return launch_switchoff_dbg<4>(stream, p, epilogue, grid);
+        case 5: return launch_switchoff_dbg<5>(stream, p, epilogue, grid);
+        case 6: return launch_switchoff_dbg<6>(stream, p, epilogue, grid);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
 #endif
 
 // Entry used by vit_gemm.hip's dispatcher.  Needs at least 4 K steps per tile (K >= 128).

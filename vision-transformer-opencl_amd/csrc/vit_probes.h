@@ -18,16 +18,14 @@
 extern "C" {
 #endif
 
-/* process-wide override of vithip_gemm_args.tile (0 = none); 101-105, 125, 126, 129 = timing-only / stamped builds */
+/* process-wide override of vithip_gemm_args.tile (0 = none); 101-105, 125, 126, 129 = timing-only / stamped builds,
+ * 131-136 = the persistent walk with one part switched off (tools/gemm_f32_switchoff.py) */
 int vithip_gemm_set_tile(int tile);
 int vithip_gemm_set_group(int group_m);           /* override of vithip_gemm_args.group_m (0 = none) */
 int vithip_gemm_set_debug_buffer(void *buf);      /* 8 x u64 stamps per workgroup for the stamped builds */
 
-/* overrides of vithip_gemm_bf16_args.variant (0 none; 3, 4 = stamped / event-log builds), .two_barriers (as
- * one_barrier: 1 / 0, -1 none) and .stagger (-1 none) */
+/* override of vithip_gemm_bf16_args.variant (0 none; 3, 4 = stamped / event-log builds) */
 int vithip_gemm_bf16_set_variant(int variant);
-int vithip_gemm_bf16_set_sync(int one_barrier);
-int vithip_gemm_bf16_set_stagger(int units);
 int vithip_gemm_bf16_set_max_workgroups(int n);   /* cap on persistent workgroups of the event-log build */
 int vithip_gemm_bf16_set_debug_buffer(void *buf);
 

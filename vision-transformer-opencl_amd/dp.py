@@ -58,10 +58,15 @@ def verify_gather(packed, gathered, expect_first_labels=None, group=None) -> boo
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    ok = tuple(gathered.shape) == (world,) + tuple(packed.shape)
-    for r in range(world if ok else 0):
+    shape_ok = tuple(gathered.shape) == (world,) + tuple(packed.shape)
+    ok = shape_ok
+    # every rank runs every broadcast whatever it has found so far (a rank that skipped them would leave the others waiting in
+    # theirs); only the comparisons depend on the local shape, and the all_reduce below carries the verdict to everybody
+    for r in range(world):
         theirs = packed.clone()
         dist.broadcast(theirs, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+        if not shape_ok:
+            continue
         ok = ok and bool(torch.equal(gathered[r], theirs))
         if expect_first_labels is not None:
             k = len(expect_first_labels)

@@ -48,7 +48,6 @@ struct vit_engine {
     void *gemm_ws[VIT_MAX_LANES]; /* per lane in use (= per stream): vithip_gemm_args.workspace handles */
     long handover_taken, handover_recomputed;
     int n_cus;                   /* compute units of the device */
-    int lane_wgs;                /* set per chunk: vithip_gemm_bf16_args.max_workgroups of its launches (0 = all) */
     /* use_graph: the captured forward and what it was captured for */
     vithip_graph_t graph;
     const float *g_images; float *g_probs; int *g_label; float *g_prob; int g_n;
@@ -133,7 +132,6 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->gemm_tile = 0;
     opt->ln_fold = 0;
     opt->gemm_handover_test = 0;
-    opt->lane_split = 0;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -495,7 +493,6 @@ static int gemm16(vit_engine *e, vithip_stream_t s, int stage, const unsigned sh
     memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = res; a.ldr = ldc;
     a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
-    a.max_workgroups = e->lane_wgs;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_bf16(s, &a));
     HIP_TRY(e, stage_end(e, s));
@@ -511,7 +508,6 @@ static int gemm16_ln(vit_engine *e, vithip_stream_t s, int stage, const unsigned
     memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = Wf; a.ldw = K; a.bias = bias_f; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
     a.ln_rows = rows; a.ln_colsum = colsum;
-    a.max_workgroups = e->lane_wgs;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_bf16(s, &a));
     HIP_TRY(e, stage_end(e, s));
@@ -524,7 +520,6 @@ static int gemm16_res_stats(vit_engine *e, vithip_stream_t s, int stage, const u
     a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = x; a.ldr = ldx; a.C = x; a.ldc = ldx;
     a.M = M; a.N = N; a.K = K; a.epilogue = VITHIP_BF16_EPI_F32_RESIDUAL;
     a.x16 = x16; a.ldx16 = ldx; a.row_partials = partials;
-    a.max_workgroups = e->lane_wgs;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_bf16(s, &a));
     HIP_TRY(e, stage_end(e, s));
@@ -580,7 +575,6 @@ typedef struct {
     unsigned short *x16;
     float *ln_part, *ln_rows, *cls_rows;
     int strips;
-    int lane_wgs;                /* persistent workgroups a lane's bf16 launches may take (0 = the whole device): opt.lane_split */
 } chunk_ctx;
 
 #define LANES for (int j = 0; j < c->L; ++j)
@@ -756,7 +750,7 @@ static int layer_bf16_folded(chunk_ctx *c, float **lw, unsigned short **lw16, co
         RUN(gemm16_ln(e, LN_.s, VIT_STAGE_QKV, c->x16 + ROWS(j) * D, D, f16, ff + 3 * D, ff, c->ln_rows + ROWS(j) * 2, c->qkv16 + ROWS(j) * 3 * D, 3 * D, LN_.n * T, 3 * D, D, VITHIP_BF16_EPI_BF16));
     LANES {
         HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
-        HIP_TRY(e, vithip_attention_bf16io_qscaled(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, T, c->lane_wgs));
+        HIP_TRY(e, vithip_attention_bf16io_qscaled(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, T));
         HIP_TRY(e, stage_end(e, LN_.s));
     }
     LANES /* out_proj + residual; bf16(x) and row sums for LN2 */
@@ -793,7 +787,7 @@ static int layer_bf16_folded_pruned(chunk_ctx *c, float **lw, unsigned short **l
     }
     LANES {
         HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
-        HIP_TRY(e, vithip_attention_bf16io_qscaled(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, 1, c->lane_wgs));
+        HIP_TRY(e, vithip_attention_bf16io_qscaled(LN_.s, c->qkv16 + ROWS(j) * 3 * D, c->y16 + ROWS(j) * D, LN_.n, T, heads, 1));
         HIP_TRY(e, stage_end(e, LN_.s));
     }
     LANES
@@ -848,8 +842,6 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
     c->ln_rows = c->ln_part + (size_t)c->strips * B * T * 2;
     c->cls_rows = c->ln_rows + B * T * 2;
 
-    /* lane_split: with L lanes every lane's persistent bf16 launches take 1/L of the CUs (see vithip_gemm_bf16_args.max_workgroups) */
-    c->lane_wgs = e->lane_wgs = (e->opt.lane_split && c->L > 1 && e->n_cus >= 2 * c->L) ? e->n_cus / c->L : 0;
     if (c->L > 1) { /* fork: the other lanes start after everything already queued on s */
         HIP_TRY(e, vithip_event_record(e->ev_fork, s));
         for (int j = 1; j < c->L; ++j) HIP_TRY(e, vithip_stream_wait_event(c->lane[j].s, e->ev_fork));
