@@ -21,6 +21,10 @@ Extra objects in the line:
   c_surface     N = 1: the same batch through vit_engine_forward_host -- what ViT_opencl(ImageData*, Network*, float**) does
                 underneath (separately allocated host images in, host probability rows out: H2D and D2H inside the time,
                 Main.c:55-60 times exactly that call).  Never `value`.
+  other_configs N = 1, default configuration only: BASELINE.json configs[2] (ViT-B/16 bf16, batch 2048) and configs[4] (ViT-L/16-384
+                bf16, batch 1024) as short timed runs of their own AFTER everything above (1 warm-up + 3 timed forwards each, batch
+                resident in HBM, the two golden images of the model open the batch: tests/golden/vit_b16_e2e.npz /
+                vit_l16_384_e2e.npz): value, ms_per_step, dominant kernel's roofline fraction, golden block.  Never `value`.
   cpu_baseline  the reference's own ViT_seq() (oracle/_ref, compiled from its ViT_seq.c) when that library is
                 present, else the CPU oracle (bit-identical restatement), timed on one host core on one
                 image of the same batch; the GPU row for that image is checked against it (1e-4 on
@@ -48,6 +52,21 @@ STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it at the met
     "attn": "attention_f32_resident_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
     "softmax": "softmax_top1_f32_kernel",
 }
+
+
+WEIGHT_SEED = 1234      # synthetic weights of every configuration (the golden fixtures were written with it)
+GOLDEN_FILE = {"b16": "vit_b16_e2e.npz", "l16_384": "vit_l16_384_e2e.npz"}   # tests/golden/: oracle/gen_golden.py, gen_golden_vit_l.py
+
+
+def load_golden(np, model, weight_seed):
+    """(probabilities [2][classes], image seed) of the two golden images of `model`, or (None, None)."""
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", GOLDEN_FILE[model]))
+    except (OSError, KeyError):
+        return None, None
+    if int(g["weight_seed"]) != weight_seed:
+        return None, None
+    return g["probs"].astype(np.float32), int(g["image_seed"])
 
 
 PROFILE_ROUND = "r03"   # profiles/<round>/: the committed rocprofv3 passes the replayed counter fields come from
@@ -184,6 +203,116 @@ def stage_macs(cfg, batch):
     }
 
 
+def dominant_kernel(times, cfg, B, dtype, kernel_steps, saved=None):
+    """Per-kernel launch time and algorithmic FLOPs from the engine's stage brackets (one lane, every launch alone on the
+    GPU) -> (name, record, average launch ms, achieved TFLOP/s) of the kernel with the most time, + all-GEMM ms and FLOPs."""
+    saved = saved or {}
+    macs = stage_macs(cfg, B)
+    per_kernel = {}
+    for stage, rec in times["stages"].items():
+        k = STAGE_KERNEL[stage]
+        if dtype == "bf16" and stage == "embed":
+            k = "gemm_bf16_pp_kernel<F32_EMBED>"
+        if dtype == "bf16" and stage == "attn":
+            k = "attention_bf16_kernel" if cfg.tokens <= 224 else "attention_bf16_stream_kernel"
+        if dtype == "bf16" and stage in ("qkv", "outproj", "fc1", "fc2"):
+            k = "gemm_bf16_pp_kernel<%s>" % {"qkv": "BF16", "fc1": "BF16_GELU", "outproj": "F32_RESIDUAL", "fc2": "F32_RESIDUAL"}[stage]
+        d = per_kernel.setdefault(k, {"ms": 0.0, "launches": 0, "flop": 0.0})
+        d["ms"] += rec["ms"]
+        d["launches"] += rec["launches"]
+        # per step: depth launches of the full size, minus what a pruned last layer skips (its extra small launches
+        # are in rec["launches"] and rec["ms"]; the flops below are the executed ones either way)
+        per_step = {"embed": 1, "head": 1}.get(stage, cfg.depth if stage in macs and macs[stage] else 0)
+        d["flop"] += 2.0 * (macs[stage] * per_step - B * saved.get(stage, 0)) * kernel_steps
+    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = dom["ms"] / max(dom["launches"], 1)
+    achieved = dom["flop"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    gemm_ms = sum(v["ms"] for k, v in per_kernel.items() if k.startswith("gemm"))
+    gemm_flop = sum(v["flop"] for k, v in per_kernel.items() if k.startswith("gemm"))
+    return dom_name, dom, avg_ms, achieved, gemm_ms, gemm_flop
+
+
+def workload_name(model, dtype, batch, config):
+    return (f"{'ViT-B/16 224x224' if model == 'b16' else 'ViT-L/16 384x384'} {'fp32' if dtype == 'f32' else 'bf16-MFMA'} forward, "
+            f"batch {batch} per GPU, synthetic weights and images (BASELINE.json configs[{config}])")
+
+
+def other_config(pkg, binding, torch, np, dev, device_index, config, weights=None, steps=3, warmup=1):
+    """BASELINE.json configs[2] / configs[4] as a short timed run of their own in the process that has just measured the headline
+    (outside its timed region, rank 0 of an N = 1 run only): same protocol -- batch resident in HBM, the two golden images open
+    the batch, `warmup` untimed and `steps` timed forwards bracketed by synchronisation, then a one-lane pass with every launch
+    bracketed for the dominant kernel's rate -- so that the driver-run line carries these configurations too.  Never `value`."""
+    model, dtype, B, lanes = {2: ("b16", "bf16", 2048, 2), 4: ("l16_384", "bf16", 1024, 2)}[config]
+    cfg = pkg.VIT_B16 if model == "b16" else pkg.VIT_L16_384
+    t_setup = time.perf_counter()
+    if weights is None:
+        weights = pkg.synth.make_weights(cfg, WEIGHT_SEED)
+    eng = binding.Engine(cfg, max_batch=B, device=device_index, profile=False, lanes=lanes, dtype=dtype)
+    eng.load_weights(weights)
+    del weights
+    n_distinct = 8
+    host_imgs = pkg.synth.make_images(cfg, n_distinct, seed=99)
+    golden, image_seed = load_golden(np, model, WEIGHT_SEED)
+    if golden is not None:
+        host_imgs[:2] = pkg.synth.make_images(cfg, 2, seed=image_seed)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        base = torch.from_numpy(host_imgs).to(dev)
+        images = base.repeat((B + n_distinct - 1) // n_distinct, 1, 1, 1)[:B].contiguous()
+        off = torch.arange(B, device=dev, dtype=torch.float32)
+        off[:n_distinct] = 0.0
+        images += 1e-3 * off.view(B, 1, 1, 1)
+        probs = torch.empty((B, cfg.num_classes), device=dev, dtype=torch.float32)
+        top1 = torch.empty((2, B), device=dev, dtype=torch.int32)
+    stream.synchronize()
+
+    def step():
+        eng.forward_device(images.data_ptr(), B, probs.data_ptr(), top1[0].data_ptr(), top1[1].data_ptr(), stream.cuda_stream)
+
+    def fence():
+        stream.synchronize()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        step()
+    fence()
+    setup_s = time.perf_counter() - t_setup
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tol = 2e-2
+    gold = None
+    if golden is not None:
+        got2 = probs[:2].cpu().numpy()
+        gold = {"rows": 2, "max_abs_prob_err": float(np.abs(got2 - golden).max()),
+                "top1_match": bool((got2.argmax(1) == golden.argmax(1)).all()), "tolerance": tol,
+                "fixture": "tests/golden/" + GOLDEN_FILE[model]}
+    eng.set_lanes(1)
+    eng.set_profile(True)
+    step()
+    fence()
+    eng.reset_stage_times()
+    step()
+    fence()
+    times = eng.stage_times()
+    eng.close()
+    dom_name, dom, avg_ms, achieved, gemm_ms, gemm_flop = dominant_kernel(times, cfg, B, dtype, 1)
+    value = B * steps / dt
+    tflops = value * 2.0 * cfg.macs_per_image / 1e12
+    return {"workload": workload_name(model, dtype, B, config), "dtype": dtype, "value": round(value, 2), "unit": "images/sec",
+            "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "lanes_per_gpu": lanes,
+            "setup_seconds": round(setup_s, 2),
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 4),
+                         "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
+                         "whole_model_tflops": round(tflops, 2), "whole_model_frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "stage_ms_per_step": {s_: round(r["ms"], 3) for s_, r in times["stages"].items()}},
+            "golden": gold,
+            "ok": gold is None or (gold["top1_match"] and gold["max_abs_prob_err"] <= tol)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +355,9 @@ def main() -> None:
     ap.add_argument("--no-c-surface", action="store_true", help="skip the host-pointer (ViT_opencl-shaped) timing after the timed region")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip roofline.clock_limit_probe (the dominant GEMM shape once on random and once on all-zero operands)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip other_configs (short timed runs of BASELINE.json configs[2] and [4] after the headline's timed region; "
+                         "only the default N = 1 configs[1] run does them)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes from this process even for --gpus 1 (N > 1 always does when not "
                          "already launched): exercises the launcher and the RCCL gather at world size 1")
@@ -243,6 +375,13 @@ def main() -> None:
     # `rocprofv3 -- python3 bench.py` profiles the process it launched.
     pkg = importlib.import_module("vision-transformer-opencl_amd")
     launch = pkg.launch
+    if not launch.launched() and args.gpus > 1:
+        # fail fast, before any rank exists: counting devices does not initialise the GPU (and this parent never does)
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, it shows {have} (one rank per GPU; "
+                     f"nothing was started)")
     if not launch.launched() and (args.gpus > 1 or args.spawn):
         rc, _ = launch.launch_ranks(os.path.abspath(__file__), [a for a in sys.argv[1:] if a != "--spawn"], args.gpus)
         sys.exit(rc)
@@ -263,15 +402,19 @@ def main() -> None:
         sys.exit(2)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():
-        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()}")
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        # every rank leaves (nobody waits in a rendezvous for a rank that cannot exist); rank 0 says why
+        if rank == 0:
+            print(f"bench.py: --gpus {world} needs {world} GPUs on this node, it shows {torch.cuda.device_count()} (one rank per GPU)",
+                  file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         launch.init_process_group("nccl", dev)
 
     B = args.batch
-    weights = synth.make_weights(cfg, 1234)
+    weights = synth.make_weights(cfg, WEIGHT_SEED)
     # per-launch HIP-event brackets are on during the timed steps when every kernel runs alone (lanes = 1);
     # with concurrent lanes they would time overlapping kernels, so the roofline pass runs after (below)
     eng = binding.Engine(cfg, max_batch=B, device=local_rank, profile=(args.lanes == 1 and not args.graph and not args.no_stage_brackets), lanes=args.lanes,
@@ -283,13 +426,13 @@ def main() -> None:
     n_distinct = min(B, 8)
     host_imgs = synth.make_images(cfg, n_distinct, seed=99 + 1000 * rank)
     golden = None
-    if args.model == "b16" and B >= 2:
+    if B >= 2:
         # images 0 and 1 of EVERY rank's batch are the two golden images (generated from the seed the fixture records; the
-        # fixture holds what the reference's own ViT_seq() made of them with the seed-1234 weights used above)
-        g = np.load(os.path.join(ROOT, "tests", "golden", "vit_b16_e2e.npz"))
-        if int(g["weight_seed"]) == 1234:
-            golden = g["probs"].astype(np.float32)
-            host_imgs[:2] = synth.make_images(cfg, 2, seed=int(g["image_seed"]))
+        # fixture holds what the reference's own ViT_seq() made of them with the seed-1234 weights used above -- for ViT-L/16-384,
+        # which the reference's macros cannot express, what the parametrised oracle pinned to it at B/16 made of them)
+        golden, golden_image_seed = load_golden(np, args.model, WEIGHT_SEED)
+        if golden is not None:
+            host_imgs[:2] = synth.make_images(cfg, 2, seed=golden_image_seed)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         base = torch.from_numpy(host_imgs).to(dev)
@@ -334,7 +477,8 @@ def main() -> None:
     if golden is not None:  # rows 0-1 of the timed steps' output against the reference's probabilities, on this rank
         got2 = probs[:2].cpu().numpy()
         gold = {"rows": 2, "max_abs_prob_err": float(np.abs(got2 - golden).max()),
-                "top1_match": bool((got2.argmax(1) == golden.argmax(1)).all()), "tolerance": tol}
+                "top1_match": bool((got2.argmax(1) == golden.argmax(1)).all()), "tolerance": tol,
+                "fixture": "tests/golden/" + GOLDEN_FILE[args.model], "ranks": 1}
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -378,29 +522,8 @@ def main() -> None:
     model_tflops = value * gflop_img / 1e3 / world  # per GPU
 
     # ---- roofline of the dominant kernel (per-launch, from the stage brackets) -------------------
-    macs = stage_macs(cfg, B)
-    per_kernel = {}
     peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-    for stage, rec in times["stages"].items():
-        k = STAGE_KERNEL[stage]
-        if args.dtype == "bf16" and stage == "embed":
-            k = "gemm_bf16_pp_kernel<F32_EMBED>"
-        if args.dtype == "bf16" and stage == "attn":
-            k = "attention_bf16_kernel" if cfg.tokens <= 224 else "attention_bf16_stream_kernel"
-        if args.dtype == "bf16" and stage in ("qkv", "outproj", "fc1", "fc2"):
-            k = "gemm_bf16_pp_kernel<%s>" % {"qkv": "BF16", "fc1": "BF16_GELU", "outproj": "F32_RESIDUAL", "fc2": "F32_RESIDUAL"}[stage]
-        d = per_kernel.setdefault(k, {"ms": 0.0, "launches": 0, "flop": 0.0})
-        d["ms"] += rec["ms"]
-        d["launches"] += rec["launches"]
-        # per step: depth launches of the full size, minus what a pruned last layer skips (its extra small launches
-        # are in rec["launches"] and rec["ms"]; the flops below are the executed ones either way)
-        per_step = {"embed": 1, "head": 1}.get(stage, cfg.depth if stage in macs and macs[stage] else 0)
-        d["flop"] += 2.0 * (macs[stage] * per_step - B * saved.get(stage, 0)) * kernel_steps
-    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
-    avg_ms = dom["ms"] / max(dom["launches"], 1)
-    achieved = dom["flop"] / max(dom["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    gemm_ms = sum(v["ms"] for k, v in per_kernel.items() if k.startswith("gemm"))
-    gemm_flop = sum(v["flop"] for k, v in per_kernel.items() if k.startswith("gemm"))
+    dom_name, dom, avg_ms, achieved, gemm_ms, gemm_flop = dominant_kernel(times, cfg, B, args.dtype, kernel_steps, saved)
     tag = profile_tag(args.dtype, args.model)
     traffic, traffic_src = pmc_traffic(dom_name, tag, B)
     busy, clock = pmc_mfma(dom_name, tag, B)
@@ -511,9 +634,21 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_clock_probe and not args.prune_last_layer:
         roofline["clock_limit_probe"] = clock_limit_probe(binding, torch, dev, cfg, B if args.lanes == 1 else B // args.lanes, args.dtype)
 
+    # ---- the other single-GPU configurations of BASELINE.json, each as a short timed run of its own (N = 1, headline only) ----------
+    others = None
+    headline = args.model == "b16" and args.dtype == "f32" and B == 256 and not args.prune_last_layer and not args.graph
+    if rank == 0 and world == 1 and not distributed and headline and not args.no_other_configs:
+        eng.close()                       # the headline engine's work is done: its 2 GB go back before the larger batches
+        del images, probs
+        torch.cuda.empty_cache()
+        others = [other_config(pkg, binding, torch, np, dev, local_rank, 2, weights=weights),
+                  other_config(pkg, binding, torch, np, dev, local_rank, 4)]
+
     ok = (gather_ok is not False) and (gold is None or (gold["top1_match"] and gold["max_abs_prob_err"] <= tol))
     if parity is not None:
         ok = ok and parity["top1_match"] and parity["max_abs_prob_err"] <= parity["tolerance"]
+    if others:
+        ok = ok and all(o["ok"] for o in others)
     if rank == 0:
         info = binding.device_info(local_rank)
         print(json.dumps({
@@ -521,14 +656,12 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": (f"{'ViT-B/16 224x224' if args.model == 'b16' else 'ViT-L/16 384x384'} "
-                                    f"{'fp32' if args.dtype == 'f32' else 'bf16-MFMA'} forward, batch {B} per GPU, synthetic weights and images "
-                                    "(BASELINE.json configs[%d])" % (args.config or (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2)))),
+            "config": {"workload": workload_name(args.model, args.dtype, B, args.config or (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2))),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                        "top1_gather": ("rccl all_gather, 8 B per image" + ("" if gather_ok else " (MISMATCH)")) if distributed else None,
                        "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "ln_fold": (args.ln_fold >= 0) if args.dtype == "bf16" else False, "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "golden": gold, "c_surface": c_surface, "ok": ok,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "golden": gold, "c_surface": c_surface, "other_configs": others, "ok": ok,
         }))
     eng.close()
     if distributed:

@@ -144,6 +144,63 @@ def test_facade_on_all_devices_of_the_node():
     assert float(np.abs(single[:2] - g["probs"][:2]).max()) <= 1e-4
 
 
+def _forward_with_top1(eng, dev, imgs, classes):
+    """One device-resident forward that leaves the packed top-1 records [2][n] (labels | probability bits) in HBM."""
+    import ctypes as C
+    L = B.lib()
+    B.hip_check(L.vithip_set_device(dev), "vithip_set_device")
+    n = imgs.shape[0]
+    d_img, d_probs, d_top1 = B.DeviceArray.from_numpy(imgs), B.DeviceArray((n, classes)), B.DeviceArray((2, n), np.int32)
+    eng.forward_device(d_img.ptr, n, d_probs.ptr, d_top1.ptr, d_top1.ptr + 4 * n, 0)
+    eng.sync()
+    return d_img, d_probs, d_top1
+
+
+def test_c_abi_rccl_gather_of_top1_records(small):
+    """include/vit_dp.h (libvit_mi355x_dp.so): N engines driven through vit_engine_forward_device from one process gather their
+    per-image top-1 records with one grouped ncclAllGather on device memory.  On this box: a communicator group of size 1 -- the
+    gathered block must equal the local records, which must equal the probabilities' arg-max -- and, where the node has
+    several GPUs, every device's gathered buffer against every device's own records (the shard axis is the reference's image
+    loop, ViT_opencl.c:802)."""
+    import ctypes as C
+    cfg, W, imgs = small
+    n_dev = C.c_int()
+    B.hip_check(B.lib().vithip_device_count(C.byref(n_dev)), "vithip_device_count")
+    for devices in ([0], list(range(n_dev.value)) if n_dev.value >= 2 else None):
+        if devices is None:
+            continue
+        nd = len(devices)
+        per = 4                                             # images per device
+        engines, held, sends, recvs = [], [], [], []
+        for r, d in enumerate(devices):
+            eng = B.Engine(cfg, max_batch=per, device=d)
+            eng.load_weights(W)
+            engines.append(eng)
+            held.append(_forward_with_top1(eng, d, imgs[(r * per) % 8:(r * per) % 8 + per], cfg.num_classes))
+            sends.append(held[-1][2].ptr)
+            recvs.append(B.DeviceArray((nd, 2, per), np.int32))
+        group = B.DpGroup(devices)
+        assert B.dp_lib().vit_dp_size(group._h) == nd and B.dp_lib().vit_dp_device(group._h, 0) == devices[0]
+        group.gather_top1(sends, [x.ptr for x in recvs], per)      # default streams
+        own = []
+        for r, d in enumerate(devices):
+            B.hip_check(B.lib().vithip_set_device(d), "vithip_set_device")
+            probs, top1 = held[r][1].numpy(), held[r][2].numpy()
+            assert np.array_equal(top1[0], probs.argmax(1)) and np.array_equal(top1[1].view(np.float32), probs.max(1))
+            own.append(top1)
+        for r, d in enumerate(devices):
+            B.hip_check(B.lib().vithip_set_device(d), "vithip_set_device")
+            got = recvs[r].numpy()
+            for q in range(nd):
+                assert np.array_equal(got[q], own[q]), (devices, r, q)
+        group.close()
+        for eng in engines:
+            eng.close()
+        B.hip_check(B.lib().vithip_set_device(0), "vithip_set_device")
+    with pytest.raises(B.VitError):
+        B.DpGroup([0, 0])                                   # a group holds a device once
+
+
 def test_fp32_chunk_is_capped_below_2gib_per_launch():
     """ViT-L/16-384 fp32: one image's MLP hidden rows are 9.45 MB, so 227 images fill the 2 GiB a buffer descriptor
     addresses (max_batch 256 used to fail mid-layer with hipErrorInvalidValue).  The engine now cuts the chunk."""
@@ -199,6 +256,25 @@ def test_bench_config3_preset_is_bf16_2048_per_gpu():
     # us (power limit, cooling), reported in the line and never asserted here
     probe = rec["roofline"]["clock_limit_probe"]
     assert probe["shape_mnk"] == [1024 * 197, 2304, 768] and probe["random_operands_tflops"] > 0 and probe["zero_operands_tflops"] > 0, probe
+
+
+def test_bench_default_line_carries_the_other_single_gpu_configs():
+    """`python bench.py` as the driver runs it (N = 1, configs[1]) also times BASELINE.json configs[2] and configs[4] after the
+    headline's timed region and reports them under other_configs, each with its golden block: ViT-B/16 bf16 against the
+    reference's own probabilities, ViT-L/16-384 bf16 against tests/golden/vit_l16_384_e2e.npz (2e-2, identical top-1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VIT_LAUNCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-c-surface", "--no-clock-probe"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["dtype"] == "f32" and rec["config"]["batch_per_gpu"] == 256 and rec["ok"] is True
+    assert rec["golden"]["fixture"] == "tests/golden/vit_b16_e2e.npz" and rec["golden"]["max_abs_prob_err"] <= 1e-4
+    others = rec["other_configs"]
+    assert [("configs[2]" in o["workload"], "configs[4]" in o["workload"]) for o in others] == [(True, False), (False, True)]
+    for o, fixture in zip(others, ("tests/golden/vit_b16_e2e.npz", "tests/golden/vit_l16_384_e2e.npz")):
+        assert o["dtype"] == "bf16" and o["value"] > 0 and o["ok"] is True
+        assert o["golden"]["fixture"] == fixture and o["golden"]["top1_match"] and o["golden"]["max_abs_prob_err"] <= 2e-2
+        assert 0 < o["roofline"]["frac"] < 1 and o["roofline"]["kernel"].startswith("gemm_bf16_pp_kernel")
 
 
 @pytest.mark.parametrize("n_images", [6, 5])

@@ -21,15 +21,23 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def test_library_exports_every_declared_symbol():
     L = B.lib()
-    declared = set()
+    declared, declared_dp = set(), set()
     for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
         text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
         for m in re.finditer(r"^[A-Za-z_][\w \*]*?\b(\w+)\s*\([^;{]*\)\s*;", text, flags=re.M):
-            declared.add(m.group(1))
+            (declared_dp if os.path.basename(h) == "vit_dp.h" else declared).add(m.group(1))
     assert {"ViT_hip", "ViT_opencl", "initialize_opencl", "Release_opencl", "load_weights", "load_image_data",
             "comparator", "vithip_gemm_f32", "vit_engine_forward_device"} <= declared
     missing = [name for name in sorted(declared) if not hasattr(L, name)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"
+    # include/vit_dp.h is the surface of libvit_mi355x_dp.so (the RCCL gather: the only library that links a collective library)
+    Ldp = B.dp_lib()
+    assert {"vit_dp_create", "vit_dp_gather_top1", "vit_dp_destroy"} <= declared_dp
+    assert not [name for name in sorted(declared_dp) if not hasattr(Ldp, name)]
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", B.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed and "nccl" not in needed          # the forward library itself has no collective dependency
+    assert "librccl" in subprocess.run(["readelf", "-d", B.DP_LIB_PATH], capture_output=True, text=True, check=True).stdout
 
 
 def test_product_library_has_no_probe_entry_points_or_tuning_setters():
@@ -228,8 +236,16 @@ def test_synthetic_generator_c_equals_numpy():
     for lo, hi in ((-0.035, 0.035), (0.5, 1.0), (-2.1, 2.6)):
         assert np.array_equal(B.synth_uniform(11, 4, 10007, lo, hi), synth.uniform(11, 4, 10007, lo, hi))
     cfg = synth.VIT_SMALL
-    for a, b in zip(B.synth_weights_c(cfg, 21), synth.make_weights(cfg, 21, native=False)):
+    want = synth.make_weights(cfg, 21, native=False)
+    for a, b in zip(B.synth_weights_c(cfg, 21), want):
         assert np.array_equal(a, b)
+    # vit_synth_weights() itself (what vit_main and a C caller use): the same tensors in a Network[] it allocates
+    L = B.lib()
+    nets = (B.CNetwork * cfg.n_weights)()
+    assert L.vit_synth_weights(C.byref(B.CConfig.of(cfg)), 21, nets, cfg.n_weights) == 0
+    for i, b in enumerate(want):
+        assert nets[i].size == b.size and np.array_equal(np.ctypeslib.as_array(nets[i].data, shape=(b.size,)), b.ravel())
+    L.free_weights(nets, cfg.n_weights)
     assert np.array_equal(B.synth_images_c(cfg, 2, 9), synth.make_images(cfg, 2, 9))
 
 

@@ -50,6 +50,25 @@ def test_end_to_end_matches_reference_vectors(oracle):
         assert np.array_equal(stages.astype(np.float64).sum(axis=(1, 2)), g["stage_sum"][i])
 
 
+def test_vit_l16_384_fixture_is_what_the_oracle_computes(oracle):
+    """tests/golden/vit_l16_384_e2e.npz (oracle/gen_golden_vit_l.py): BASELINE.json configs[4] at its real size.  The reference
+    has no ViT-L (its dimensions are macros, ViT_seq.c:10-21): the fixture is the PARAMETRISED restatement's output -- the one
+    pinned bit for bit against the compiled reference at ViT-B/16 above -- and this re-runs image 0 (24 layers, 577 tokens: about
+    25 s on 8 cores) and compares bit for bit, so that the file cannot drift from the oracle the GPU tests and bench.py trust it
+    for.  Image 1 is covered by the generator's own run; its row in the file is checked for shape and for being a distribution."""
+    g = np.load(os.path.join(GOLD, "vit_l16_384_e2e.npz"))
+    cfg = synth.VIT_L16_384
+    assert int(g["n_images"]) == 2 and g["probs"].shape == (2, 1000) and g["logits"].shape == (2, 1000)
+    assert g["cls_rows"].shape == (2, cfg.depth + 1, cfg.embed_dim)
+    assert np.allclose(g["probs"].sum(1), 1.0, atol=1e-5) and (g["probs"].argmax(1) == g["logits"].argmax(1)).all()
+    W = synth.make_weights(cfg, int(g["weight_seed"]))
+    img = synth.make_images(cfg, 1, int(g["image_seed"]))[0]
+    probs, logits, stages = oracle.forward_image(oracle_config(cfg), img, W, want_stages=True)
+    assert same_bits(probs, g["probs"][0])
+    assert same_bits(logits, g["logits"][0])
+    assert same_bits(stages[:, 0, :], g["cls_rows"][0])
+
+
 def test_reference_answer_fixture_is_well_formed():
     """Data/answer_result.txt of the reference (100 lines `[i] label: L / prob: P`), kept as a fixture
     for the blob-present KAT; Data/input-100.bin and 36 weight files are absent upstream."""

@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 stats() {  # name, bench args...
     local name=$1; shift
     timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/$name" -- \
-        python3 bench.py --no-cpu-baseline --no-c-surface --no-clock-probe "$@" > "$OUT/bench_$name.json" 2> "$W/$name.err"
+        python3 bench.py --no-cpu-baseline --no-c-surface --no-clock-probe --no-other-configs "$@" > "$OUT/bench_$name.json" 2> "$W/$name.err"
     cp "$(find "$W/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_$name.csv"
     echo "stats $name done"
 }
@@ -21,7 +21,7 @@ pmc() {  # name, counter, bench args...
     local name=$1 ctr=$2; shift 2
     # shellcheck disable=SC2086  ($ctr may hold several counter names)
     timeout -k 10 500 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$W/$name" -- \
-        python3 bench.py --no-cpu-baseline --no-c-surface --no-clock-probe --lanes 1 --steps 2 --warmup 1 "$@" > /dev/null 2> "$W/$name.err"
+        python3 bench.py --no-cpu-baseline --no-c-surface --no-clock-probe --no-other-configs --lanes 1 --steps 2 --warmup 1 "$@" > /dev/null 2> "$W/$name.err"
     echo "pmc $name done"
 }
 
@@ -41,7 +41,7 @@ if [ "$2" != "f32only" ]; then
     python3 tools/mfma_summary.py "$W/bf16_mfma" "$OUT/mfma_util_bf16.csv"
     # BASELINE.json configs[4]: ViT-L/16-384, batch 1024, bf16: unprofiled line, kernel stats, HBM traffic and matrix-pipe passes
     L16="--model l16_384 --dtype bf16 --batch 1024"
-    timeout -k 10 500 python3 bench.py --no-cpu-baseline --no-c-surface --no-clock-probe $L16 --steps 3 --warmup 1 \
+    timeout -k 10 500 python3 bench.py --no-cpu-baseline --no-c-surface --no-clock-probe --no-other-configs $L16 --steps 3 --warmup 1 \
         > "$OUT/bench_bf16_l16_384_batch1024.json" 2> "$W/l16.err"
     stats bf16_l16_384_batch1024 $L16 --steps 3 --warmup 1
     pmc l16_fetch FETCH_SIZE $L16

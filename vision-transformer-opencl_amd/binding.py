@@ -73,6 +73,55 @@ class CGemmArgs(C.Structure):
 _lib: Optional[C.CDLL] = None
 
 
+DP_LIB_PATH = os.path.join(HERE, "libvit_mi355x_dp.so")
+_dp_lib = None
+
+
+def dp_lib() -> C.CDLL:
+    """libvit_mi355x_dp.so (include/vit_dp.h): the RCCL all-gather of the top-1 records behind the C-ABI."""
+    global _dp_lib
+    if _dp_lib is None:
+        if not os.path.exists(DP_LIB_PATH):
+            raise VitError(f"{DP_LIB_PATH} is missing: run `make -C {HERE}`")
+        L = C.CDLL(DP_LIB_PATH)
+        L.vit_dp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+        L.vit_dp_destroy.argtypes = [C.c_void_p]
+        L.vit_dp_destroy.restype = None
+        L.vit_dp_size.argtypes = [C.c_void_p]
+        L.vit_dp_device.argtypes = [C.c_void_p, C.c_int]
+        L.vit_dp_last_error.argtypes = [C.c_void_p]
+        L.vit_dp_last_error.restype = C.c_char_p
+        L.vit_dp_gather_top1.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p)]
+        _dp_lib = L
+    return _dp_lib
+
+
+class DpGroup:
+    """vit_dp (include/vit_dp.h): one RCCL communicator per listed device of this process."""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        rc = dp_lib().vit_dp_create(C.byref(self._h), arr, len(self.devices))
+        if rc != 0:
+            raise VitError(f"vit_dp_create({self.devices}) failed: {rc}")
+
+    def gather_top1(self, send_ptrs, recv_ptrs, records: int, streams=None) -> None:
+        n = len(self.devices)
+        send = (C.c_void_p * n)(*send_ptrs)
+        recv = (C.c_void_p * n)(*recv_ptrs)
+        st = (C.c_void_p * n)(*streams) if streams is not None else None
+        rc = dp_lib().vit_dp_gather_top1(self._h, send, recv, records, st)
+        if rc != 0:
+            raise VitError(f"vit_dp_gather_top1: {dp_lib().vit_dp_last_error(self._h).decode()} ({rc})")
+
+    def close(self) -> None:
+        if self._h:
+            dp_lib().vit_dp_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 def lib() -> C.CDLL:
     """Load the native library; never falls back to anything else."""
     global _lib
@@ -757,16 +806,22 @@ def synth_uniform(seed: int, index: int, n: int, lo: float, hi: float) -> np.nda
 
 
 def synth_weights_c(cfg: ModelConfig, seed: int):
-    """The C generator (vit_synth_weights); must equal synth.make_weights bit for bit."""
+    """The C generator (vit_synth_uniform + vit_round_weights of the host library, the pair vit_synth_weights() runs per tensor),
+    filling numpy arrays in place; must equal synth.make_weights(native=False) bit for bit (tests/test_host_io.py)."""
+    from .synth import _RANGE, _kind
     L = lib()
-    cc = CConfig.of(cfg)
-    nets = (CNetwork * cfg.n_weights)()
-    if L.vit_synth_weights(C.byref(cc), seed, nets, cfg.n_weights) != 0:
-        raise VitError("vit_synth_weights: out of memory")
-    shapes = cfg.weight_shapes()
-    out = [np.ctypeslib.as_array(nets[i].data, shape=(nets[i].size,)).copy().reshape(shapes[i])
-           for i in range(cfg.n_weights)]
-    L.free_weights(nets, cfg.n_weights)
+    L.vit_synth_uniform.argtypes = [C.c_ulonglong, C.c_int, C.c_size_t, C.c_float, C.c_float, C.c_void_p]
+    L.vit_synth_uniform.restype = None
+    L.vit_round_weights.argtypes = [C.c_void_p, C.c_size_t]
+    L.vit_round_weights.restype = None
+    out = []
+    for i, shape in enumerate(cfg.weight_shapes()):
+        kind = _kind(cfg, i)
+        lo, hi = (0.5, 1.0) if kind == "ln_w" else (-_RANGE[kind], _RANGE[kind])
+        w = np.empty(shape, np.float32)
+        L.vit_synth_uniform(seed, i, w.size, lo, hi, w.ctypes.data)
+        L.vit_round_weights(w.ctypes.data, w.size)
+        out.append(w)
     return out
 
 
