@@ -44,7 +44,7 @@ def test_gemm_bf16_identity_asymmetric_exact(variant):
 
 @pytest.mark.parametrize("M,N,K", [(512, 768, 768), (197, 2304, 768), (300, 100, 64), (1000, 768, 3072), (5, 12, 128)])
 def test_gemm_bf16_residual_fp32_out(oracle, variant, M, N, K):
-    if variant == 2 and K < 128:
+    if variant >= 2 and K < 128:
         pytest.skip("ping-pong kernel needs two K steps; auto mode uses the two-stage kernel here")
     Ab, Wb = B.to_bf16_bits(u(2, (M, K), 1.0)), B.to_bf16_bits(u(3, (N, K), 0.05))
     b, R = u(4, (N,), 0.1), u(5, (M, N), 2.0)

@@ -20,6 +20,8 @@ fold = len(sys.argv) > 3 and sys.argv[3] == "fold"
 T, D = (197, 768) if model == "b16" else (577, 1024)
 M = batch * T
 SHAPES = {"qkv": (M, 3 * D, D, 0), "outproj": (M, D, D, 2), "fc1": (M, 4 * D, D, 1), "fc2": (M, D, 4 * D, 2)}
+VARIANTS = [int(v) for v in os.environ.get("VIT_TOOL_VARIANTS", "0").split(",")]   # vithip_gemm_bf16_args.variant: 0 auto, 1 two-stage, 2 ping-pong (A/B in one process)
+ROUNDS = int(os.environ.get("VIT_TOOL_ROUNDS", "3"))
 out = {}
 for name, (M_, N, K, epi) in SHAPES.items():
     rng = np.random.default_rng(0)
@@ -45,9 +47,16 @@ for name, (M_, N, K, epi) in SHAPES.items():
         tail = (extra[0].ptr, extra[1].ptr, None, 0, None)
     else:
         tail = (None, None, None, 0, None)
-    args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi, 0, *tail)
-    ms = min(timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=5, warm=2) for _ in range(3))
-    out[name] = {"ms": round(ms, 4), "tflops": round(2.0 * M_ * N * K / (ms * 1e-3) / 1e12, 1)}
+    ms = {v: [] for v in VARIANTS}
+    for _ in range(ROUNDS):   # interleaved rounds in one process on one device: the only comparison that means anything
+        for v in VARIANTS:
+            args = B.CGemmBf16Args(dA.ptr, K, dW.ptr, K, db.ptr, dC.ptr if epi == 2 else None, N, dC.ptr, N, M_, N, K, epi, v, *tail)
+            ms[v].append(timed(lambda: B.hip_check(L.vithip_gemm_bf16(None, C.byref(args))), reps=5, warm=2))
+    out[name] = {("variant%d" % v if len(VARIANTS) > 1 else "auto"): {"ms_min": round(min(t), 4), "ms_median": round(sorted(t)[len(t) // 2], 4),
+                                                                       "tflops": round(2.0 * M_ * N * K / (min(t) * 1e-3) / 1e12, 1)}
+                 for v, t in ms.items()}
+    if len(VARIANTS) == 1:
+        out[name] = out[name]["auto"] | {"ms": out[name]["auto"]["ms_min"]}
     for d in [dA, dW, db, dC] + extra:
         d.free()
-print(json.dumps({"library": os.path.basename(B.LIB_PATH), "data": os.environ.get("VIT_TOOL_DATA", "random"), "batch": batch, "model": model, "fold": fold, **out}))
+print(json.dumps({"batch": batch, "model": model, "fold": fold, "data": os.environ.get("VIT_TOOL_DATA", "random"), "gemms": out}))

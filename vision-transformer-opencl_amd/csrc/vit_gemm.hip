@@ -374,7 +374,14 @@ int launch_probe(hipStream_t stream, GemmParams &p) {
 
 template <int AMODE>
 int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int group_m) {
-    p.group_m = group_m > 0 ? group_m : 8;  // tile rows per L2 group of the XCD-aware walk
+    // Tile rows per L2 group of the XCD-aware walk.  Measured per launch at batch 256 (tools/gemm_f32_traffic.py, PMC FETCH_SIZE /
+    // WRITE_SIZE passes, round 4), bytes from beyond the L2s over algorithmic: N = 768 (6 tile columns: fc2 / out_proj) 3.11 / 1.58
+    // with groups of 8 rows, 2.34 / 1.34 in plain N-fastest order (group 1: the 64 tiles an XCD holds at a time are ~11 whole tile
+    // rows, every A panel read by one XCD instead of two); wide N (QKV 18 columns, fc1 24) 2.90 / 2.82 with 8, 2.81 / 2.71 with 4,
+    // 3.6-4.6 with 1, 2 or 16.  The launch TIMES do not move with any of this (+-0.3 %, same tool): the extra reads are served by
+    // the Infinity Cache, not by HBM -- the choice is bytes, not milliseconds.
+    const int cols128 = (p.N + 127) / 128;
+    p.group_m = group_m > 0 ? group_m : (cols128 <= 8 ? 1 : 4);
 #ifdef VIT_PROBES
     if (g_gemm_tile) tile = g_gemm_tile;
     if (g_gemm_group) p.group_m = g_gemm_group;

@@ -307,6 +307,7 @@ bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) ==
 int g_variant = 0;  // 0 none, 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong, 4 event-log ping-pong
 unsigned long long *g_dbg = nullptr;
 int g_max_wgs = 0;    // event-log build: cap on persistent workgroups (0 = one per CU)
+int g_group16 = 0;    // tile rows per L2 group of the walk (0 = the launcher's choice)
 #endif
 
 }  // namespace
@@ -328,6 +329,12 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
 int vithip_gemm_bf16_set_variant(int variant) {
     if (variant < 0 || variant > 4) return static_cast<int>(hipErrorInvalidValue);
     g_variant = variant;
+    return 0;
+}
+
+int vithip_gemm_bf16_set_group(int group_m) {
+    if (group_m < 0 || group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
+    g_group16 = group_m;
     return 0;
 }
 
@@ -405,7 +412,9 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.tiles_m = (p.M + TBM - 1) / TBM;
     p.tiles_n = (p.N + TBN - 1) / TBN;
-    p.group_m = 8;
+    // tile rows per L2 group of the walk (tools/gemm_bf16_group.py, batch 2048, round 4): N = 768 (three tile columns: out_proj,
+    // fc2) fetches 6.56 GB per fc2 launch with groups of 8 rows and 4.95 GB with 2, at 1 % less time; wide N (QKV, fc1) is best at 8
+    p.group_m = p.tiles_n <= 4 ? 2 : 8;
     if (a->variant < 0 || a->variant > 2) return static_cast<int>(hipErrorInvalidValue);
     // LayerNorm fold: consumer (ln_rows + ln_colsum on the bf16 epilogues) or producer (x16 + row_partials on the residual one)
     const bool ln_consumer = a->ln_rows || a->ln_colsum, ln_producer = a->x16 || a->row_partials;
@@ -426,6 +435,7 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     }
     int variant = a->variant;
 #ifdef VIT_PROBES
+    if (g_group16) p.group_m = g_group16;
     if (g_variant) variant = g_variant;
 #endif
     const int g_cus = vitdev::current_cus();  // of the current device, asked per call (engines of several devices share the process)

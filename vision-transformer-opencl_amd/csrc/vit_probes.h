@@ -26,6 +26,7 @@ int vithip_gemm_set_debug_buffer(void *buf);      /* 8 x u64 stamps per workgrou
 
 /* override of vithip_gemm_bf16_args.variant (0 none; 3, 4 = stamped / event-log builds) */
 int vithip_gemm_bf16_set_variant(int variant);
+int vithip_gemm_bf16_set_group(int group_m);      /* tile rows per L2 group of the bf16 tile walk (0 = the launcher's choice) */
 int vithip_gemm_bf16_set_max_workgroups(int n);   /* cap on persistent workgroups of the event-log build */
 int vithip_gemm_bf16_set_debug_buffer(void *buf);
 
