@@ -119,3 +119,27 @@ def test_vit_main_streams_chunks_and_uses_the_packed_cache(tree):
     assert "Weight_*.bin files" in outs["cache-write"][1] and (root / "w.cache").exists()
     assert "packed cache" in outs["cache-read"][1]
     assert "on 2 devices" in outs["two-engines"][1]
+
+
+def test_c_caller_gathers_top1_over_rccl(tmp_path):
+    """tests/dropin/dp_caller.c: a plain-C program drives one vit_engine per device through vit_engine_forward_device (weights
+    uploaded once, replicated device to device), gathers the per-image top-1 records with vit_dp_gather_top1 -- ONE grouped
+    ncclAllGather on the engines' streams, include/vit_dp.h -- and checks every device's gathered buffer against every device's
+    own records and those against the probabilities.  One device here (a communicator of size 1); every device of the node too
+    when it has several."""
+    import ctypes as C
+    exe = tmp_path / "dp_caller"
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, "tests", "dropin", "dp_caller.c"), "-o", str(exe), f"-L{PKG}", "-lvit_mi355x", "-lvit_mi355x_dp",
+           f"-Wl,-rpath,{PKG}", "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n_dev = C.c_int()
+    B.hip_check(B.lib().vithip_device_count(C.byref(n_dev)), "vithip_device_count")
+    runs = [["5", "0"]] + ([["3"] + [str(d) for d in range(n_dev.value)]] if n_dev.value >= 2 else [])
+    for args in runs:
+        r = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"dp_caller ok devices={len(args) - 1} images={int(args[0]) * (len(args) - 1)}" in r.stdout
+    r = subprocess.run([str(exe), "2", "0", "0"], capture_output=True, text=True, timeout=600)   # a device twice: refused, not hung
+    assert r.returncode != 0 and "vit_dp_create" in r.stderr
