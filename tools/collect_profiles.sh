@@ -9,7 +9,7 @@ OUT=gpurun_out/profiles/$R
 W=gpurun_out/prof_work
 rm -rf "$W" "$OUT"; mkdir -p "$W" "$OUT"
 export TMPDIR=/tmp
-export VIT_DEVICE=$(python3 -c "import importlib,sys; sys.path.insert(0,'.'); b=importlib.import_module('vision-transformer-opencl_amd.binding'); i=b.device_info(0); print(i['name'], '(' + i['arch'] + ',', i['compute_units'], 'CUs)')" 2>/dev/null)
+export VIT_DEVICE=$(python3 -c "import importlib,sys; sys.path.insert(0,'.'); b=importlib.import_module('vision-transformer-opencl_amd.binding'); i=b.device_info(0); print((i['name'] or 'MI355X pool box'), '(' + i['arch'] + ',', i['compute_units'], 'CUs)')" 2>/dev/null)
 
 stats() {  # name, bench args...
     local name=$1; shift

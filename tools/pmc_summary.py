@@ -101,14 +101,13 @@ def main():
     import os
     import subprocess
     dev = os.environ.get("VIT_DEVICE")   # tools/collect_profiles.sh: name and arch as the library's vithip_get_device_info reports them
-    try:   # provenance: bench.py marks these figures as replayed (roofline.replayed_from)
-        if dev:
-            raise LookupError
-        dev = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
-        names = [ln.split(":", 1)[1].strip() for ln in dev.splitlines() if "Marketing Name" in ln]
-        dev = next((n for n in names if "Instinct" in n or "Radeon" in n or "MI3" in n), None)
-    except Exception:
-        dev = None
+    if not dev:
+        try:   # provenance: bench.py marks these figures as replayed (roofline.replayed_from)
+            txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
+            names = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if "Marketing Name" in ln]
+            dev = next((n for n in names if "Instinct" in n or "Radeon" in n or "MI3" in n), None)
+        except Exception:
+            dev = None
     with open(out + ".json", "w") as f:
         json.dump({"unit": "bytes per launch", "batch": batch, "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
                    "device": dev, "commit": os.environ.get("VIT_COMMIT"),
