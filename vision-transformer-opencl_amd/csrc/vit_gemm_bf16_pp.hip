@@ -310,6 +310,10 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
         // just finished (nobody reads or fills that slot before the next phase 1, which is behind a barrier).
         // Inline asm: hipcc would put `s_waitcnt vmcnt(0)` in front of ordinary LDS loads that follow LDS stores
         // while LDS-DMA is in flight (it cannot tell these buffers from the DMA ring) and drain the prefetch queue.
+        // (Every inline-asm store below ends in `s_nop 1`: the next vector instruction may overwrite the store's data registers, and the
+        // wait states a store of more than 8 bytes needs in front of such a write are padded by hipcc for its own instructions only.
+        // Found in round 4 on an experimental epilogue -- a v_mov in the slot behind a store cost it single dwords, differently from
+        // run to run; the shipped epilogues had the same exposure and only their register allocation kept them clear of it.)
         const unsigned lds0 = (unsigned)(size_t)(lds_void *)lds;
         const unsigned buf_a = lds0 + SCRATCH + wave * 2048;
         const unsigned buf_b = lds0 + ((par ^ 1) * 4 + 3) * SLOT + wave * 2048;
@@ -478,9 +482,9 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                     }
                     if constexpr (SADDR) {
                         if (INTERIOR || in_range(blk, 0))
-                            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(c_l), "v"(ya), "s"(c_s + blk_bytes(blk, 0, p.ldc, 4)) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(c_l), "v"(ya), "s"(c_s + blk_bytes(blk, 0, p.ldc, 4)) : "memory");
                         if (INTERIOR || in_range(blk, 1))
-                            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(c_l), "v"(yb), "s"(c_s + blk_bytes(blk, 1, p.ldc, 4)) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(c_l), "v"(yb), "s"(c_s + blk_bytes(blk, 1, p.ldc, 4)) : "memory");
                     } else {
                         if (INTERIOR || in_range(blk, 0)) *reinterpret_cast<f32x4 *>(ca) = ya;
                         if (INTERIOR || in_range(blk, 1)) *reinterpret_cast<f32x4 *>(cb) = yb;
@@ -510,12 +514,12 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                                 const uint2 ra = swap2(odd ? keep_a : ca), rb = swap2(odd ? keep_b : cb);  // even lanes send their block-1 piece
                                 const u32x4 oa = odd ? u32x4{ra.x, ra.y, ca.x, ca.y} : u32x4{keep_a.x, keep_a.y, ra.x, ra.y};
                                 const u32x4 ob = odd ? u32x4{rb.x, rb.y, cb.x, cb.y} : u32x4{keep_b.x, keep_b.y, rb.x, rb.y};
-                                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(x_lw), "v"(oa), "s"(x_s + blk_bytes(blk - 1, 0, p.ldx16, 2)) : "memory");
-                                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(x_lw), "v"(ob), "s"(x_s + blk_bytes(blk - 1, 1, p.ldx16, 2)) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(x_lw), "v"(oa), "s"(x_s + blk_bytes(blk - 1, 0, p.ldx16, 2)) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(x_lw), "v"(ob), "s"(x_s + blk_bytes(blk - 1, 1, p.ldx16, 2)) : "memory");
                             }
                         } else {
-                            if (in_a) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(x_l), "v"(pk4(ya)), "s"(x_s + blk_bytes(blk, 0, p.ldx16, 2)) : "memory");
-                            if (in_b) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(x_l), "v"(pk4(yb)), "s"(x_s + blk_bytes(blk, 1, p.ldx16, 2)) : "memory");
+                            if (in_a) asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(x_l), "v"(pk4(ya)), "s"(x_s + blk_bytes(blk, 0, p.ldx16, 2)) : "memory");
+                            if (in_b) asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(x_l), "v"(pk4(yb)), "s"(x_s + blk_bytes(blk, 1, p.ldx16, 2)) : "memory");
                         }
                         // columns outside N add nothing; rows outside M are summed but never stored
                         const f32x4 za = in_a ? ya : f32x4{0.f, 0.f, 0.f, 0.f}, zb = in_b ? yb : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -527,8 +531,8 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                             const int i16 = (blk >> 1) * 16;
                             const f32x2 ta = f32x2{sum8_dpp(ps_a + sa), sum8_dpp(pq_a + qa)}, tb = f32x2{sum8_dpp(ps_b + sb), sum8_dpp(pq_b + qb)};
                             if (ch8 == 0) {
-                                if (INTERIOR || i16 < m_left) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(p_l), "v"(ta), "s"(p_s + (size_t)i16 * 8) : "memory");
-                                if (INTERIOR || i16 + 8 < m_left) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(p_l), "v"(tb), "s"(p_s + (size_t)(i16 + 8) * 8) : "memory");
+                                if (INTERIOR || i16 < m_left) asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(p_l), "v"(ta), "s"(p_s + (size_t)i16 * 8) : "memory");
+                                if (INTERIOR || i16 + 8 < m_left) asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(p_l), "v"(tb), "s"(p_s + (size_t)(i16 + 8) * 8) : "memory");
                             }
                         }
                     }
