@@ -376,10 +376,9 @@ def main() -> None:
     pkg = importlib.import_module("vision-transformer-opencl_amd")
     launch = pkg.launch
     if not launch.launched() and args.gpus > 1:
-        # fail fast, before any rank exists: counting devices does not initialise the GPU (and this parent never does)
-        import torch
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        # fail fast, before any rank exists; the count is taken in a child interpreter (this parent imports neither torch nor HIP)
+        have = launch.visible_gpus()
+        if 0 <= have < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, it shows {have} (one rank per GPU; "
                      f"nothing was started)")
     if not launch.launched() and (args.gpus > 1 or args.spawn):
@@ -659,7 +658,7 @@ def main() -> None:
             "config": {"workload": workload_name(args.model, args.dtype, B, args.config or (4 if args.model != "b16" else (1 if args.dtype == "f32" else 2))),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                        "top1_gather": ("rccl all_gather, 8 B per image" + ("" if gather_ok else " (MISMATCH)")) if distributed else None,
-                       "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "ln_fold": (args.ln_fold >= 0) if args.dtype == "bf16" else False, "device": info["name"], "arch": info["arch"],
+                       "gflop_per_image": round(gflop_img, 4), "prune_last_layer": bool(args.prune_last_layer), "ln_fold": args.ln_fold >= 0, "device": info["name"], "arch": info["arch"],
                        "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "golden": gold, "c_surface": c_surface, "other_configs": others, "ok": ok,
         }))

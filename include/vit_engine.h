@@ -49,10 +49,13 @@ typedef struct {
                       * small batches the ~150 launches of a forward are a visible share of the latency.  Ignored
                       * while profiling, with lanes > 1 and on the NULL stream (not capturable). */
     int gemm_tile;   /* tuning: vithip_gemm_args.tile for every fp32 GEMM of this engine (0 = auto, the default) */
-    int ln_fold;     /* bf16 engines: fold the encoder LayerNorms into the GEMMs either side of them (vit_hip_kernels.h,
-                      * "LayerNorm folding"): 0 = auto (on when embed_dim and hidden_dim >= 128), 1 = on (error when the
-                      * shapes do not allow it), -1 = off (a LayerNorm kernel per LayerNorm).  Not used by fp32 engines:
-                      * the fp32 path keeps the reference's operation order. */
+    int ln_fold;     /* fold the encoder LayerNorms into the GEMMs behind them (vit_hip_kernels.h, "LayerNorm folding"): in_proj and
+                      * fc1 multiply the un-normalised rows with gamma-folded weights and rescale in their epilogues, a LayerNorm
+                      * is then one pass that reads x and writes 8 bytes per row (fp32) or nothing at all (bf16: the residual
+                      * GEMM in front produces the row sums).  0 = auto (fp32: on when embed_dim % 64 == 0 and <= 2048; bf16: on
+                      * when embed_dim and hidden_dim >= 128), 1 = on (error when the shapes do not allow it), -1 = off: a
+                      * LayerNorm kernel per LayerNorm, i.e. the reference's operation order (ViT_seq.c:103-147) -- both orders
+                      * meet the 1e-4 bar against ViT_seq.c, the folded one is not the same bits as the unfolded one. */
     int gemm_handover_test; /* testing: vithip_gemm_args.handover_test for every fp32 GEMM (1 = helper pieces arrive too late and
                              * every owner computes its whole tile; results must not change) */
 } vit_engine_options;

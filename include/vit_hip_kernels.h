@@ -109,8 +109,36 @@ typedef struct {
     /* testing: 1 = the helper workgroups run their pieces LAST, so that owners look for them too early and take the
      * compute-it-yourself path (results must not change); 0 = normal. */
     int handover_test;
+    /* LayerNorm folded into the GEMM behind it (both NULL = off; EPI_BIAS and EPI_BIAS_GELU only): A holds the UN-normalised
+     * rows x, W and bias are the gamma- and beta-folded operands of vithip_ln_fold_weights_f32(), ln_rows [M][2] = (rstd, mean)
+     * per row of A (vithip_rowstats_f32), ln_colsum [N]; the epilogue computes
+     *     fmaf(rstd, fmaf(-mean, colsum, acc), bias) = LayerNorm(x) . W^T + b                 (ViT_seq.c:103-121 is the LayerNorm)
+     * with the same two roundings in every kernel (the 32x32 kernels take the inner one as a rank-1 matrix instruction, four per
+     * wave and tile: csrc/vit_gemm_common.hpp), so that the tile shapes stay bit-identical to each other.  The
+     * normalised activations never exist in memory: the pass that wrote them (read x, write y: 310 MB at batch 256, 24 times per
+     * ViT-B/16 forward) becomes a pass that reads x and writes 8 bytes per row. */
+    const float *ln_rows, *ln_colsum;
+    /* ... and the producer side (NULL = off; EPI_BIAS_RESIDUAL only, N % 64 == 0, N <= 2048): stats_out [M][2] receives (rstd,
+     * mean) of the rows of C as stored -- what vithip_rowstats_f32(C) would write, bit for bit.  With stats_partials
+     * ([N / 64][M][2] floats of scratch) the persistent walk takes the sums in its epilogue, where the row is in the accumulators
+     * (one small launch then finalises them: vithip_gemm_f32_stats_in_epilogue() says whether a call would); any other kernel,
+     * or no scratch, and the call runs vithip_rowstats_f32 behind the GEMM. */
+    float *stats_out, *stats_partials;
 } vithip_gemm_args;
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *args);
+int vithip_gemm_f32_stats_in_epilogue(const vithip_gemm_args *args);  /* 1 / 0 (0 also for arguments vithip_gemm_f32 would refuse) */
+/* ---- LayerNorm folding, fp32: LN(x) . W^T + b = rstd * (x . (gamma*W)^T) - rstd * mean * colsum(gamma*W) + (b + W . beta).
+ * Wf[n][k] = gamma[k] * W[n][k] (fp32 product); colsum[n] = sum_k Wf[n][k] and bias_f[n] = bias[n] + sum_k beta[k] * W[n][k], both
+ * accumulated in double and rounded once.  W fp32 [N][K], K % 4 == 0, 16-byte aligned. */
+int vithip_ln_fold_weights_f32(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
+                               float *Wf, float *colsum, float *bias_f, int N, int K);
+/* rows_out[m] = (rstd, mean) of x [rows][ldx], dim % 64 == 0, dim <= 2048: mean and E[x^2] - mean^2 as ViT_seq.c:103-121
+ * takes them, 1 / sqrtf((double)var + 1e-6).  The sums run in ONE documented order (per 64-column strip: columns c and c + 32
+ * added first, then a 32-lane butterfly 16, 8, 4, 2, 1; strips in ascending order), the order a GEMM epilogue that holds the
+ * row in its accumulators can reproduce -- so that whoever produces the statistics produces the same bits. */
+int vithip_rowstats_f32(vithip_stream_t stream, const float *x, size_t ldx, float *rows_out, int rows, int dim);
+/* partials [dim / 64][rows][2] (sum, sum of squares per 64-column strip, in the order above) -> rows_out [rows][2] */
+int vithip_rowstats_finalize_f32(vithip_stream_t stream, const float *partials, int rows, int dim, float *rows_out);
 size_t vithip_gemm_f32_workspace_bytes(void);             /* device bytes a workspace takes on the current device */
 int vithip_gemm_f32_workspace_create(void **workspace);   /* on the current device */
 int vithip_gemm_f32_workspace_destroy(void *workspace);

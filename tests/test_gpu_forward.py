@@ -244,6 +244,59 @@ def test_b16_batch256_with_late_helpers_is_bit_identical(b16):
     assert st["recomputed"] > 0 and st["taken"] + st["recomputed"] == 12 * (316 + 316 + 240), st
 
 
+@pytest.mark.parametrize("prune", [False, True])
+def test_b16_batch256_row_statistics_from_the_gemm_epilogue_are_bit_identical(b16, prune):
+    """At the metric batch the two residual GEMMs of every layer take the row statistics of the LayerNorm that follows them in
+    their own epilogue (vithip_gemm_args.stats_out; csrc/vit_gemm_common.hpp): of the 25 statistics passes only layer 0's and the
+    head's LayerNorm stay launches (pruned last layer: plus the class rows' pass and the copy of their pairs).  An engine held to
+    the one-tile-per-workgroup kernel (gemm_tile = 10: a statistics pass behind every residual GEMM) must give the same bits."""
+    eng, _ = b16
+    g, imgs, idx = _batch256()
+    depth = synth.VIT_B16.depth
+    outs = {}
+    for tile in (0, 10):
+        e2 = B.Engine(synth.VIT_B16, max_batch=256, profile=True, gemm_tile=tile, prune_last_layer=prune)
+        try:
+            e2.copy_weights_from(eng)
+            outs[tile] = _forward_device(e2, imgs)
+            launches = e2.stage_times()["stages"]["ln"]["launches"]
+        finally:
+            e2.close()
+        assert launches == ((4 if prune else 2) if tile == 0 else 2 * depth + 1 + (1 if prune else 0)), (tile, launches)
+    assert np.array_equal(outs[0], outs[10])
+    assert np.array_equal(outs[0], _forward_device(eng, imgs))
+    for k in (0, 1):
+        row = outs[0][idx == k][0]
+        assert float(np.abs(row - g["probs"][k]).max()) <= PROB_TOL
+        assert int(row.argmax()) == int(g["probs"][k].argmax())
+
+
+def test_b16_layernorm_fold_fp32_stays_within_the_bar(b16):
+    """fp32 engines fold the encoder LayerNorms into in_proj / fc1 by default (vit_engine_options.ln_fold; the GEMMs multiply the
+    raw rows with gamma-folded weights and rescale in the epilogue).  That is another operation order than ViT_seq.c:103-147, so
+    it is held to the same bar: the golden rows of the reference's own ViT_seq() within 1e-4 with the same top-1, at the metric
+    batch -- and next to the unfolded engine (ln_fold = -1, the reference's order), which it must track far inside the bar."""
+    eng, _ = b16
+    g, imgs, idx = _batch256()
+    folded = _forward_device(eng, imgs)
+    plain = B.Engine(synth.VIT_B16, max_batch=256, ln_fold=-1)
+    try:
+        plain.copy_weights_from(eng)
+        unfolded = _forward_device(plain, imgs)
+    finally:
+        plain.close()
+    assert not np.array_equal(folded, unfolded)          # (the default engine does fold)
+    diff = float(np.abs(folded - unfolded).max())
+    print(f"fp32 LayerNorm fold: max |dprob| against the unfolded engine {diff:.3g}")
+    assert diff <= 2e-5
+    assert np.array_equal(folded.argmax(1), unfolded.argmax(1))
+    for out in (folded, unfolded):
+        for k in (0, 1):
+            row = out[idx == k][0]
+            assert float(np.abs(row - g["probs"][k]).max()) <= PROB_TOL
+            assert int(row.argmax()) == int(g["probs"][k].argmax())
+
+
 def test_empty_and_invalid_inputs(b16):
     """Empty input: the facade is a no-op for image[0].n == 0 (the reference's loop simply would not run,
     ViT_opencl.c:802); the engine API rejects n <= 0 and NULL rows with an error code instead of crashing."""

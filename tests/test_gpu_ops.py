@@ -129,6 +129,114 @@ def test_gemm_tile_shapes_are_bit_identical():
         assert np.array_equal(B.gemm(A[:7], W, b, residual=None if res is None else res[:7], epilogue=epi), ref[:7]), epi
 
 
+def _rowstats_model(x):
+    """vithip_rowstats_f32's documented order in numpy fp32: per 64-column strip u = x[c + l] + x[c + 32 + l] and
+    w = fma(x[c + 32 + l], x[c + 32 + l], x[c + l] * x[c + l]) for l < 32, a butterfly 16, 8, 4, 2, 1, strips ascending from 0."""
+    x = np.asarray(x, np.float32)
+    rows, dim = x.shape
+    s = np.zeros(rows, np.float32)
+    ss = np.zeros(rows, np.float32)
+    for c in range(0, dim, 64):
+        x0, x1 = x[:, c:c + 32], x[:, c + 32:c + 64]
+        u_ = x0 + x1
+        sq0 = (x0 * x0).astype(np.float32)
+        w_ = (x1.astype(np.longdouble) * x1.astype(np.longdouble) + sq0.astype(np.longdouble)).astype(np.float32)  # one rounding: the fma
+        for off in (16, 8, 4, 2, 1):
+            idx = np.arange(32) ^ off
+            u_ = u_ + u_[:, idx]
+            w_ = w_ + w_[:, idx]
+        s = s + u_[:, 0]
+        ss = ss + w_[:, 0]
+    mean = s / np.float32(dim)
+    var = ss / np.float32(dim) - mean * mean
+    rstd = (np.float32(1.0) / np.sqrt((var.astype(np.float64) + 1e-6).astype(np.float32))).astype(np.float32)
+    return np.stack([rstd, mean], axis=1)
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 64), (37, 192), (333, 768), (130, 1024), (9, 1984)])
+def test_rowstats_f32_follows_its_documented_order(rows, dim):
+    """(rstd, mean) per row, bit for bit the documented summation order (a GEMM epilogue that holds the row can reproduce
+    it), and the LayerNorm statistics of ViT_seq.c:103-121 to fp32 rounding."""
+    x = (u(60, (rows, dim), 3.0) + np.float32(0.7)).astype(np.float32)
+    got = B.rowstats_f32(x)
+    assert np.array_equal(got, _rowstats_model(x))
+    x64 = x.astype(np.float64)
+    mean, var = x64.mean(1), x64.var(1)
+    rstd = 1.0 / np.sqrt(var + 1e-6)
+    assert np.abs(got[:, 0] - rstd).max() <= 2e-6 * rstd.max() and np.abs(got[:, 1] - mean).max() <= 2e-6 * np.abs(mean).max() + 1e-6
+
+
+def test_gemm_layernorm_fold_matches_layernorm_then_gemm():
+    """LN(x) . W^T + b = rstd * (x . (gamma W)^T - mean * colsum) + (b + W . beta): the folded GEMM on the raw rows against the
+    LayerNorm kernel followed by the plain GEMM (the reference's order, ViT_seq.c:103-147), both epilogues; every tile shape gives
+    the same bits as the others (the fold's value is two fused multiply-adds, the inner one a rank-1 matrix instruction in the
+    32x32 kernels and a v_fma in the 16x16 latency kernel -- the same rounding)."""
+    M, D, N = 333, 768, 328
+    x = (u(61, (M, D), 2.0) + u(62, (1, D), 1.0)).astype(np.float32)   # rows with a common offset per column: the mean term matters
+    gamma, beta = (1.0 + u(63, (D,), 0.5)).astype(np.float32), u(64, (D,), 0.5)
+    W, b = u(65, (N, D), 0.05), u(66, (N,), 0.1)
+    Wf, colsum, bias_f = B.ln_fold_weights_f32(W, b, gamma, beta)
+    assert np.array_equal(Wf, (gamma[None, :] * W).astype(np.float32))
+    assert np.allclose(colsum, (gamma[None, :].astype(np.float64) * W).sum(1), rtol=0, atol=2e-6)
+    assert np.allclose(bias_f, b + W.astype(np.float64) @ beta.astype(np.float64), rtol=0, atol=2e-6)
+    rows = B.rowstats_f32(x)
+    y = B.layernorm(x, gamma, beta)
+    for epi in (B.EPI_BIAS, B.EPI_BIAS_GELU):
+        want = B.gemm(y, W, b, epilogue=epi, tile=10)
+        ref = B.gemm(x, Wf, bias_f, epilogue=epi, tile=10, ln=(rows, colsum))
+        err = float(np.abs(ref - want).max())
+        assert err <= 2e-5, (epi, err)      # values of order 1: a few fp32 ulps of the un-normalised accumulation
+        for tile in (0, 6, 7, 8, 9, 11, 12):
+            assert np.array_equal(B.gemm(x, Wf, bias_f, epilogue=epi, tile=tile, ln=(rows, colsum)), ref), (epi, tile)
+        assert np.array_equal(B.gemm(x[:7], Wf, bias_f, epilogue=epi, ln=(rows[:7], colsum)), ref[:7]), epi
+    with pytest.raises(B.VitError):    # the fold is a property of the bias / bias+GELU epilogues
+        B.gemm(x, Wf, bias_f, residual=np.zeros((M, N), np.float32), epilogue=B.EPI_BIAS_RESIDUAL, ln=(rows, colsum))
+
+
+def test_gemm_layernorm_fold_persistent_walk_with_helper_pieces():
+    """The fold in the persistent walk: the rows' pairs travel through LDS (fetched when a tile begins, published in its last
+    K-step); 600 tiles on 512 workgroups with a workspace, so that tiles started by a helper are finished -- and rescaled -- by
+    their owner; a ragged last row block.  Same bits as the one-tile-per-workgroup kernel."""
+    M, D, N = 128 * 49 + 57, 768, 1536
+    x = (u(67, (M, D), 2.0) + u(68, (1, D), 1.0)).astype(np.float32)
+    gamma, beta = (1.0 + u(69, (D,), 0.5)).astype(np.float32), u(70, (D,), 0.5)
+    W, b = u(71, (N, D), 0.05), u(72, (N,), 0.1)
+    Wf, colsum, bias_f = B.ln_fold_weights_f32(W, b, gamma, beta)
+    rows = B.rowstats_f32(x)
+    for epi in (B.EPI_BIAS, B.EPI_BIAS_GELU):
+        ref = B.gemm(x, Wf, bias_f, epilogue=epi, tile=10, ln=(rows, colsum))
+        for late in (0, 1):
+            st = {}
+            got = B.gemm(x, Wf, bias_f, epilogue=epi, tile=9, workspace=True, handover_test=late, stats=st, ln=(rows, colsum))
+            assert np.array_equal(got, ref), (epi, late)
+            assert st["taken"] + st["recomputed"] > 0, st
+        assert np.array_equal(B.gemm(x, Wf, bias_f, epilogue=epi, tile=9, ln=(rows, colsum)), ref), epi
+
+
+@pytest.mark.parametrize("M,N,K", [(128 * 49 + 57, 768, 768), (128 * 40, 1024, 256), (128 * 171, 768, 128), (300, 768, 128), (128 * 30, 192, 128)])
+def test_gemm_residual_row_statistics_in_the_epilogue(M, N, K):
+    """vithip_gemm_args.stats_out: (rstd, mean) of the rows a residual GEMM stores.  The persistent walk takes the sums in
+    its epilogue (a lane's two accumulator columns first, then a reduce-scatter in the butterfly order), one launch finalises them;
+    every other kernel is followed by vithip_rowstats_f32.  Whoever produces them, they are the bits of vithip_rowstats_f32 on
+    the stored C, and C is what the plain residual GEMM stores.  Shapes: helper pieces + a ragged row block, 1024 columns with
+    short tiles, 1,026 tiles (the auto rule picks the persistent walk), a small problem, a width that is not whole 128-column tiles
+    (never in the epilogue)."""
+    A, W, b, R = u(80, (M, K), 1.0), u(81, (N, K), 0.05), u(82, (N,), 0.1), (u(83, (M, N), 2.0) + u(84, (1, N), 1.0)).astype(np.float32)
+    ref = B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL, tile=10)
+    want = B.rowstats_f32(ref)
+    for tile, ws, late in ((9, True, 0), (9, True, 1), (9, False, 0), (0, True, 0), (10, False, 0)):
+        st = {}
+        got = B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL, tile=tile, workspace=ws, handover_test=late, row_stats=st)
+        assert np.array_equal(got, ref), (tile, ws, late)
+        assert np.array_equal(st["rows"], want), (tile, ws, late, st["in_epilogue"])
+        assert st["in_epilogue"] == int(N % 128 == 0 and (tile == 9 or (tile == 0 and (M + 127) // 128 * (N // 128) >= 1024))), (tile, st)
+    st = {"scratch": False}     # no scratch lent: the statistics pass runs behind the GEMM
+    assert np.array_equal(B.gemm(A, W, b, residual=R, epilogue=B.EPI_BIAS_RESIDUAL, tile=9, row_stats=st), ref)
+    assert st["in_epilogue"] == 0 and np.array_equal(st["rows"], want)
+    with pytest.raises(B.VitError):
+        B.gemm(A, W, b, epilogue=B.EPI_BIAS, row_stats={})
+
+
 def test_gemm_helper_pieces_are_bit_identical_and_reusable():
     """Persistent walk with a workspace: the tiles of the partial last round start on an idle workgroup and finish on their
     owner (csrc/vit_gemm_persistent.hip).  600 tiles on 512 workgroups: 88 owners hand 12 of 24 K-steps to a helper.  The

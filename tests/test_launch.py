@@ -44,8 +44,9 @@ def test_launcher_reports_a_failed_rank_and_stops_the_rest():
 
 def test_bench_parent_spawns_before_touching_torch_or_hip():
     """`python bench.py --gpus 2` started plainly must become a launcher: the parent may not import torch or load the
-    HIP library (a process that has initialised the GPU must not start workers).  No GPU here, so the ranks exit with
-    bench.py's "needs a GPU" message -- what is checked is who imported what, and that the failure is relayed."""
+    HIP library (a process that has initialised the GPU must not start workers).  It counts the node's GPUs in a child
+    interpreter first and fails fast when there are fewer than ranks -- no GPU here, so that is what happens: what is checked is
+    who imported what, and that nothing was started."""
     code = (
         "import sys, runpy, os\n"
         "sys.argv = ['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '2', '--no-cpu-baseline']\n"
@@ -56,11 +57,22 @@ def test_bench_parent_spawns_before_touching_torch_or_hip():
         "bad = [m for m in sys.modules if m == 'torch' or m.endswith('.binding')]\n"
         "print('PARENT', rc, bad)\n" % ROOT)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VIT_LAUNCH_CHILD")}
-    env["HIP_VISIBLE_DEVICES"] = ""      # keep the rank processes off any GPU: this is the CPU suite
+    env["HIP_VISIBLE_DEVICES"] = ""      # keep every process off any GPU: this is the CPU suite
     env["CUDA_VISIBLE_DEVICES"] = ""
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     last = [l for l in r.stdout.splitlines() if l.startswith("PARENT")][-1]
     assert last.endswith("[]"), r.stdout + r.stderr              # neither torch nor the binding in the parent
-    assert " 0 " not in last                                      # ranks failed (no GPU) and the parent said so
+    assert "needs 2 GPUs on this node, it shows 0" in last and "nothing was started" in last, last
+    assert "[rank" not in r.stderr, r.stderr                      # no rank ever ran
+
+
+def test_a_rank_without_a_gpu_says_so_and_the_launcher_relays_it(capsys):
+    """The ranks' own check (a launcher whose count could not be taken starts them anyway): `bench.py` as a launched rank on a
+    box without a GPU exits with "needs a GPU", and launch_ranks relays the message and the failure."""
+    from importlib import import_module
+    launch = import_module("vision-transformer-opencl_amd.launch")
+    rc, _ = launch.launch_ranks(os.path.join(ROOT, "bench.py"), ["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline"],
+                                2, timeout=600, extra_env={"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert rc != 0
     # whichever rank fails first stops the other (launch_ranks terminates the rest), so only ONE message is guaranteed
-    assert re.search(r"\[rank [01]\] .*needs a GPU", r.stderr), r.stderr
+    assert re.search(r"\[rank [01]\] .*needs a GPU", capsys.readouterr().err)

@@ -67,7 +67,8 @@ class CGemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("epilogue", C.c_int), ("tile", C.c_int), ("group_m", C.c_int), ("workspace", C.c_void_p),
-                ("handover_test", C.c_int)]
+                ("handover_test", C.c_int), ("ln_rows", C.c_void_p), ("ln_colsum", C.c_void_p),
+                ("stats_out", C.c_void_p), ("stats_partials", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -256,10 +257,13 @@ class DeviceArray:
 
 
 def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: int = 0, workspace: bool = False,
-         handover_test: int = 0, stats: Optional[dict] = None) -> np.ndarray:
+         handover_test: int = 0, stats: Optional[dict] = None, ln=None, row_stats: Optional[dict] = None) -> np.ndarray:
     """C = epilogue(A . W^T + bias) through vithip_gemm_f32 (tile / group_m: per-call tuning fields, 0 = auto;
     workspace: lend the scratch that enables the helper pieces of the persistent walk; handover_test: see
-    vithip_gemm_args; stats: receives the hand-over counters {"taken", "recomputed"} of the launch)."""
+    vithip_gemm_args; stats: receives the hand-over counters {"taken", "recomputed"} of the launch;
+    ln = (rows [M][2], colsum [N]): the consumer side of the LayerNorm fold, W / bias being the folded operands;
+    row_stats: a dict that receives "rows" = vithip_gemm_args.stats_out [M][2] and "in_epilogue" = what
+    vithip_gemm_f32_stats_in_epilogue said; its key "scratch" (default True) lends stats_partials)."""
     A, W, bias = _as_f32(A), _as_f32(W), _as_f32(bias)
     M, K = A.shape
     N = W.shape[0]
@@ -267,10 +271,19 @@ def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: i
     dC = DeviceArray((M, N))
     dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
     ws = gemm_workspace() if workspace else None
+    dRows = DeviceArray.from_numpy(_as_f32(ln[0])) if ln is not None else None
+    dCs = DeviceArray.from_numpy(_as_f32(ln[1])) if ln is not None else None
+    dSt = DeviceArray((M, 2)) if row_stats is not None else None
+    dPart = DeviceArray((max(N // 64, 1), M, 2)) if row_stats is not None and row_stats.get("scratch", True) else None
     args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue, tile, group_m, ws,
-                     handover_test)
+                     handover_test, dRows.ptr if dRows else None, dCs.ptr if dCs else None, dSt.ptr if dSt else None,
+                     dPart.ptr if dPart else None)
+    if row_stats is not None:
+        row_stats["in_epilogue"] = int(lib().vithip_gemm_f32_stats_in_epilogue(C.byref(args)))
     hip_check(lib().vithip_gemm_f32(None, C.byref(args)), "vithip_gemm_f32")
     out = dC.numpy()
+    if row_stats is not None:
+        row_stats["rows"] = dSt.numpy()
     if ws:
         if stats is not None:
             stats.update(gemm_workspace_stats(ws))
@@ -460,6 +473,29 @@ def layernorm(x, gamma, beta) -> np.ndarray:
     dy = DeviceArray((rows, dim))
     hip_check(lib().vithip_layernorm_f32(None, dx.ptr, dim, dy.ptr, dim, dg.ptr, db.ptr, rows, dim), "vithip_layernorm_f32")
     return dy.numpy()
+
+
+def ln_fold_weights_f32(W, bias, gamma, beta):
+    """vithip_ln_fold_weights_f32 -> (Wf [N][K], colsum [N], bias_f [N])."""
+    W, bias, gamma, beta = _as_f32(W), _as_f32(bias), _as_f32(gamma), _as_f32(beta)
+    N, K = W.shape
+    dW, db, dg, dbe = (DeviceArray.from_numpy(a) for a in (W, bias, gamma, beta))
+    dWf, dcs, dbf = DeviceArray((N, K)), DeviceArray((N,)), DeviceArray((N,))
+    lib().vithip_ln_fold_weights_f32.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int]
+    hip_check(lib().vithip_ln_fold_weights_f32(None, dW.ptr, db.ptr, dg.ptr, dbe.ptr, dWf.ptr, dcs.ptr, dbf.ptr, N, K),
+              "vithip_ln_fold_weights_f32")
+    return dWf.numpy(), dcs.numpy(), dbf.numpy()
+
+
+def rowstats_f32(x) -> np.ndarray:
+    """vithip_rowstats_f32 -> [rows][2] = (rstd, mean)."""
+    x = _as_f32(x)
+    rows, dim = x.shape
+    L = lib()
+    L.vithip_rowstats_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    dx, dr = DeviceArray.from_numpy(x), DeviceArray((rows, 2))
+    hip_check(L.vithip_rowstats_f32(None, dx.ptr, dim, dr.ptr, rows, dim), "vithip_rowstats_f32")
+    return dr.numpy()
 
 
 def attention(qkv, n_images: int, tokens: int, heads: int) -> np.ndarray:

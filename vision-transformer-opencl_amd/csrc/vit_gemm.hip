@@ -172,6 +172,15 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
         const int n = n0 + wn * WN + j * 32 + r;
         bias_r[j] = n < p.N ? p.bias[n] : 0.0f;
     }
+    FoldOperands<TN> fold{};  // LayerNorm fold (consumer): the folded weight's column sums beside the bias, the rows' pairs from memory
+    if constexpr (EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + r;
+            fold.colsum[j] = n < p.N ? p.ln_colsum[n] : 0.0f;
+        }
+        fold.rows = reinterpret_cast<const f32x2 *>(p.ln_rows) + m0;
+    }
 
     const int nk = p.K / BK;
     const int a_frag_off = (wm * WM + r) * LDS_LD + h * 4;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
     }
 
     if constexpr (DBG == 5) st_clk2 = __builtin_amdgcn_s_memtime();
-    epilogue_store<BM, BN, WM, WN, EPI, AMODE>(p, acc, bias_r, m0, n0, wm, wn, r, h);
+    epilogue_store<BM, BN, WM, WN, EPI, AMODE>(p, acc, bias_r, m0, n0, wm, wn, r, h, fold);
     if constexpr (DBG == 5) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long c3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
@@ -353,6 +362,12 @@ int launch_tile(hipStream_t stream, GemmParams &p, int epilogue) {
                 break;
             case VITHIP_EPI_BIAS_RESIDUAL:
                 hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS_RESIDUAL, A_DENSE, 0, BK, PIPE>), grid, block, 0, stream, p);
+                break;
+            case EPI_BIAS_LN:
+                hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WM, WN, EPI_BIAS_LN, A_DENSE, 0, BK, PIPE>), grid, block, 0, stream, p);
+                break;
+            case EPI_BIAS_GELU_LN:
+                hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WM, WN, EPI_BIAS_GELU_LN, A_DENSE, 0, BK, PIPE>), grid, block, 0, stream, p);
                 break;
             default:
                 return static_cast<int>(hipErrorInvalidValue);
@@ -454,7 +469,9 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
                 // with a workspace the persistent walk hands the first K-steps of the partial last round's tiles to idle
                 // workgroups (fc2 / out_proj at batch 256: 480 -> 448 steps per workgroup); without one the residual
                 // epilogue is marginally faster one tile per workgroup (fc2 21.30 vs 21.43 ms per step)
-                if (p.sk_ws && vitgemm::persistent_piece_steps(p.M, p.N, p.K, p.sk_slots, 0) > 0) return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
+                // (also when the caller wants the row statistics of the stored rows: the persistent epilogue takes them on the way)
+                if ((p.row_partials && p.N % 128 == 0) || (p.sk_ws && vitgemm::persistent_piece_steps(p.M, p.N, p.K, p.sk_slots, 0) > 0))
+                    return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
                 return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
             }
             if (tiles < 2048) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
@@ -553,6 +570,15 @@ int vithip_gemm_f32_workspace_stats(void *ws, int *taken, int *recomputed) {
 // The device side of the handle (tests read the flags through it).
 void *vithip_gemm_f32_workspace_device_ptr(void *ws) { return ws ? static_cast<GemmWorkspace *>(ws)->dev : nullptr; }
 
+// Would vithip_gemm_f32(a) take the row statistics in its epilogue?  (the persistent walk: tile 9, or auto with >= 1024 tiles)
+int vithip_gemm_f32_stats_in_epilogue(const vithip_gemm_args *a) {
+    if (!a || !a->stats_out || !a->stats_partials || a->epilogue != VITHIP_EPI_BIAS_RESIDUAL || a->M <= 0 || a->N <= 0 || a->N % 128 ||
+        a->N > 2048)
+        return 0;
+    const long tiles = (long)((a->M + 127) / 128) * (a->N / 128);
+    return (a->tile == 9 || (a->tile == 0 && tiles >= 1024)) ? 1 : 0;
+}
+
 int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     if (!a || !a->A || !a->W || !a->bias || !a->C) return static_cast<int>(hipErrorInvalidValue);
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->K % KALIGN != 0) return static_cast<int>(hipErrorInvalidValue);
@@ -582,7 +608,25 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     }
     if (a->handover_test < 0 || a->handover_test > 1) return static_cast<int>(hipErrorInvalidValue);
     if (a->tile < 0 || (a->tile > 0 && a->tile < 6) || a->tile > 12 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
-    return dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, a->epilogue, a->tile, a->group_m);
+    int epilogue = a->epilogue;
+    if (a->ln_rows || a->ln_colsum) {  // LayerNorm fold, consumer side
+        if (!a->ln_rows || !a->ln_colsum || (epilogue != VITHIP_EPI_BIAS && epilogue != VITHIP_EPI_BIAS_GELU) ||
+            (reinterpret_cast<size_t>(a->ln_rows) & 7))
+            return static_cast<int>(hipErrorInvalidValue);
+        p.ln_rows = a->ln_rows;
+        p.ln_colsum = a->ln_colsum;
+        epilogue = epilogue == VITHIP_EPI_BIAS ? vitgemm::EPI_BIAS_LN : vitgemm::EPI_BIAS_GELU_LN;
+    }
+    if (a->stats_out) {  // ... producer side
+        if (epilogue != VITHIP_EPI_BIAS_RESIDUAL || a->N % 64 || a->N > 2048 || (reinterpret_cast<size_t>(a->stats_out) & 7) ||
+            (reinterpret_cast<size_t>(a->stats_partials) & 7))
+            return static_cast<int>(hipErrorInvalidValue);
+        if (vithip_gemm_f32_stats_in_epilogue(a)) p.row_partials = a->stats_partials;
+    }
+    const int rc = dispatch<A_DENSE>(static_cast<hipStream_t>(stream), p, epilogue, a->tile, a->group_m);
+    if (rc != 0 || !a->stats_out) return rc;
+    if (p.stats_in_epilogue) return vithip_rowstats_finalize_f32(stream, a->stats_partials, a->M, a->N, a->stats_out);
+    return vithip_rowstats_f32(stream, a->C, (size_t)a->ldc, a->stats_out, a->M, a->N);
 }
 
 int vithip_patch_embed_f32(vithip_stream_t stream, const float *images, const float *conv_w,

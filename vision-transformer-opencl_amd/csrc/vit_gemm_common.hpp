@@ -11,11 +11,15 @@ namespace vitgemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KALIGN = 32;  // K must be a multiple of this (covers both K steps below)
 
 enum { A_DENSE = 0, A_PATCHES = 1 };
+// epilogue codes beyond the public three (vit_hip_kernels.h): the consumer side of the LayerNorm fold (ln_rows / ln_colsum set)
+// and the producer side: the residual epilogue that also leaves the row sums of what it stored (row_partials set; persistent walk)
+enum { EPI_BIAS_LN = 3, EPI_BIAS_GELU_LN = 4, EPI_RESIDUAL_STATS = 5 };
 
 struct GemmParams {
     const float *A;
@@ -41,6 +45,13 @@ struct GemmParams {
     int sk_x;
     int sk_late;     // tests: helpers run their pieces last (vithip_gemm_args.handover_test)
     int sk_gen;      // launch number on this workspace (1 .. 2^28): flag words of other generations read as empty
+    // LayerNorm fold, consumer side (EPI_BIAS_LN, EPI_BIAS_GELU_LN): (rstd, mean) per row of A, column sums of the folded W
+    const float *ln_rows;
+    const float *ln_colsum;
+    // producer side (EPI_RESIDUAL_STATS): [N / 64][M][2] partial (sum, sum of squares) of the stored rows per 64-column strip;
+    // stats_in_epilogue: set by the dispatcher when the kernel it chose writes them (the caller then only finalises)
+    float *row_partials;
+    int stats_in_epilogue;
 };
 
 // erf(x) = sign(x) * (1 - exp(t*q(t))), t = min(|x|, 4), q = degree-7 minimax fit of log(erfc(t))/t
@@ -118,7 +129,6 @@ __device__ __forceinline__ void gelu_erf_x8(float (&y)[8]) {
 // rounding that follows, at 6.5 VALU instructions per value (6 + 1 v_pk_fma_f32, v_min, v_max, v_exp_f32 per pair and
 // value) instead of 19 for the fp32-accurate form above
 // (ViT_seq.c:231-233 is the fp32 definition; the bf16 path's parity bar is in tests/test_gpu_bf16.py).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_bf16_x2(f32x2 y) {
     constexpr float kClamp = 5.656854249492381f;  // 4 sqrt2
     const f32x2 t = f32x2{fminf(__builtin_fabsf(y.x), kClamp), fminf(__builtin_fabsf(y.y), kClamp)};
@@ -160,13 +170,76 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
 // tile, 29 % of the kernel).  Hence: the bias is passed in registers (fetched long before), interior
 // tiles take a branch-free path, and the residual / pos_emb operands of one accumulator are loaded
 // in batches before their stores.
+// LayerNorm fold, consumer side (EPI_BIAS_LN / EPI_BIAS_GELU_LN): what the epilogue needs besides the bias
+template <int TN>
+struct FoldOperands {
+    float colsum[TN];   // column sums of the folded weight at this lane's columns (fetched with the bias, long before)
+    const f32x2 *rows;  // (rstd, mean) of the tile's rows m0, m0 + 1, ...: p.ln_rows + 2 m0, or the persistent walk's LDS copy of them
+};
+// The fold's value, the same two fused multiply-adds in every kernel:
+//     acc' = fma(-mean, colsum, acc)     x . (gamma W)^T - mean * colsum(gamma W) = (x - mean) . (gamma W)^T
+//     y    = fma(rstd, acc', bias_f)
+// The 32x32 kernels take the first one as ONE more v_mfma_f32_32x32x2_f32 per accumulator -- a rank-1 update with the k = 0
+// operands (-mean of the lane's row, colsum of the lane's column) and zeros at k = 1: the instruction adds its two products to
+// the accumulator one after the other, each with one rounding (tools/probes/mfma_order_probe.hip), so the result is
+// fma(0, 0, fma(-mean, colsum, acc)) = the line above -- four matrix instructions per wave and tile instead of 64 vector ones.
+__device__ __forceinline__ float fold_center(float acc, float mean, float colsum) { return __builtin_fmaf(-mean, colsum, acc); }
+__device__ __forceinline__ float fold_scale(float centered, float rstd, float bias) { return __builtin_fmaf(rstd, centered, bias); }
+
 template <int BM, int BN, int WM, int WN, int EPI, int AMODE>
 __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16 (&acc)[WM / 32][WN / 32],
                                                const float (&bias_r)[WN / 32], int m0, int n0, int wm, int wn,
-                                               int r, int h) {
+                                               int r, int h, const FoldOperands<WN / 32> &fold = FoldOperands<WN / 32>{}) {
     constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr bool FOLD = EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN;
+    constexpr bool GELU = EPI == VITHIP_EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_LN;
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);  // workgroup-uniform
     if (interior) {
+        if constexpr (FOLD) {
+            // acc' = acc - mean * colsum as one rank-1 MFMA per accumulator: A operand = -mean of row r of the block (k = 0, lanes
+            // h = 0; the h = 1 lanes supply k = 1: zero), B operand = colsum of column r.  One 32-row block at a time: its two
+            // matrix instructions, the 16 rstd of the lane's rows (LDS reads in the persistent walk -- fetched once per block:
+            // behind the scheduling fences of the GELU batches every batch would wait for its own), then the batches.
+            const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7fffffff, 0x00020000);
+            float b_op[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b_op[j] = h == 0 ? fold.colsum[j] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int lr0 = wm * WM + i * 32;
+                const float mean = fold.rows[lr0 + r].y;
+                const float a_op = h == 0 ? -mean : 0.0f;
+                f32x16 centered[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) centered[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op, b_op[j], acc[i][j], 0, 0, 0);
+                float row_rstd[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int lr = lr0 + 4 * h + 8 * g;  // tile-local row of registers 4g .. 4g + 3
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) row_rstd[4 * g + e] = fold.rows[lr + e].x;
+                }
+                const int mb = m0 + lr0 + 4 * h;  // row of register 0
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WN + j * 32 + r;
+                    const int c_off = (mb * p.ldc + n) * 4, c_row = p.ldc * 4;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {  // two batches of 8: values first (eight erf chains in lock-step), then 8 stores
+                        float y[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) y[q] = fold_scale(centered[j][half * 8 + q], row_rstd[half * 8 + q], bias_r[j]);
+                        if constexpr (GELU) gelu_erf_x8(y);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int v = half * 8 + q;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[q]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, 0);
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + r;
@@ -218,7 +291,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
                             float y[8];
 #pragma unroll
                             for (int q = 0; q < 8; ++q) y[q] = acc[i][j][half * 8 + q] + bias_r[j];
-                            if constexpr (EPI == VITHIP_EPI_BIAS_GELU) gelu_erf_x8(y);
+                            if constexpr (GELU) gelu_erf_x8(y);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const int v = half * 8 + q;
@@ -241,13 +314,18 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
                 for (int v = 0; v < 16; ++v) {
                     const int m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                     if (n_ok && m < p.M) {
-                        float y = acc[i][j][v] + bias_r[j];
+                        float y;
+                        if constexpr (FOLD) {
+                            const f32x2 row = fold.rows[m - m0];
+                            y = fold_scale(fold_center(acc[i][j][v], row.y, fold.colsum[j]), row.x, bias_r[j]);
+                        }
+                        else y = acc[i][j][v] + bias_r[j];
                         if constexpr (AMODE == A_PATCHES) {
                             const int im = m / p.patches, pp = m - im * p.patches;
                             y += p.pos[(size_t)(pp + 1) * p.N + n];
                             p.C[((size_t)m + im + 1) * p.ldc + n] = y;
                         } else {
-                            if constexpr (EPI == VITHIP_EPI_BIAS_GELU) y = gelu_erf(y);
+                            if constexpr (GELU) y = gelu_erf(y);
                             if constexpr (EPI == VITHIP_EPI_BIAS_RESIDUAL) y += p.R[(size_t)m * p.ldr + n];
                             p.C[(size_t)m * p.ldc + n] = y;
                         }
@@ -284,5 +362,99 @@ int launch_gemm_f32_latency(hipStream_t stream, GemmParams &p, int epilogue);
 int launch_patch_embed_bf16(hipStream_t s, const float *images, const unsigned short *conv_w16, const float *conv_b,
                             const float *cls, const float *pos, float *x, int n_images, int img_size, int patch_size,
                             int in_chans, int embed_dim);
+
+// ---- residual epilogue that also leaves the row statistics' partial sums (LayerNorm fold, producer side) ---------------------
+// 16 per-lane values -> lane r of each 32-lane half holds the total of value (r >> 1) & 15 over the half's lanes, added in the
+// butterfly order 16, 8, 4, 2, 1 (own + partner at every level): the order of vithip_rowstats_f32, at 15 + 1 exchanges instead
+// of 16 x 5.
+__device__ __forceinline__ float reduce_scatter16(const float (&a)[16], int r) {
+    float b[8], c[4], d[2], e;
+    {
+        const bool up = (r & 16) != 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = (up ? a[k + 8] : a[k]) + __shfl_xor(up ? a[k] : a[k + 8], 16);
+    }
+    {
+        const bool up = (r & 8) != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = (up ? b[k + 4] : b[k]) + __shfl_xor(up ? b[k] : b[k + 4], 8);
+    }
+    {
+        const bool up = (r & 4) != 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) d[k] = (up ? c[k + 2] : c[k]) + __shfl_xor(up ? c[k] : c[k + 2], 4);
+    }
+    {
+        const bool up = (r & 2) != 0;
+        e = (up ? d[1] : d[0]) + __shfl_xor(up ? d[0] : d[1], 2);
+    }
+    return e + __shfl_xor(e, 1);
+}
+
+// C = acc + bias + residual as epilogue_store<EPI_BIAS_RESIDUAL> stores it, and p.row_partials[strip][m] = (sum, sum of squares)
+// of the stored values of row m over the wave's 64-column strip, in the documented order of vithip_rowstats_f32: column c + l and
+// c + 32 + l first (the lane's two accumulator columns), then the butterfly.  WN = 64 (one strip per wave), N % BN == 0.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_store_residual_stats(const GemmParams &p, const f32x16 (&acc)[WM / 32][WN / 32],
+                                                              const float (&bias_r)[WN / 32], int m0, int n0, int wm, int wn,
+                                                              int r, int h) {
+    static_assert(WN == 64, "one 64-column strip per wave");
+    constexpr int TM = WM / 32;
+    const bool interior = m0 + BM <= p.M;  // workgroup-uniform
+    const int strip = (n0 + wn * WN) >> 6;
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.R), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * WM + i * 32 + 4 * h;  // row of register 0
+        float y[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * WN + j * 32 + r;
+            const int c_off = (mb * p.ldc + n) * 4, c_row = p.ldc * 4, r_off = (mb * p.ldr + n) * 4, r_row = p.ldr * 4;
+            if (interior) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {  // two batches of 8 loads-then-stores, as in epilogue_store
+                    float res[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int v = half * 8 + q;
+                        res[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, r_off, ((v & 3) + 8 * (v >> 2)) * r_row, 0));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int v = half * 8 + q;
+                        y[j][v] = acc[i][j][v] + bias_r[j] + res[q];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[j][v]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = mb + (v & 3) + 8 * (v >> 2);
+                    y[j][v] = 0.0f;
+                    if (m < p.M) {
+                        y[j][v] = acc[i][j][v] + bias_r[j] + p.R[(size_t)m * p.ldr + n];
+                        p.C[(size_t)m * p.ldc + n] = y[j][v];
+                    }
+                }
+            }
+        }
+        float u[16], w[16];
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                u[v] = y[0][v] + y[1][v];
+                const float sq0 = y[0][v] * y[0][v];
+                w[v] = __builtin_fmaf(y[1][v], y[1][v], sq0);
+            }
+        }
+        const float us = reduce_scatter16(u, r), ws = reduce_scatter16(w, r);
+        const int v = (r >> 1) & 15;
+        const int m = mb + (v & 3) + 8 * (v >> 2);
+        if (!(r & 1) && m < p.M) *reinterpret_cast<f32x2 *>(p.row_partials + ((size_t)strip * p.M + m) * 2) = f32x2{us, ws};
+    }
+}
 
 }  // namespace vitgemm

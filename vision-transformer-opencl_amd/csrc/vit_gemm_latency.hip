@@ -130,8 +130,11 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_latency_kernel(const GemmPara
     for (int v = 0; v < 4; ++v) {
         const int m = m0 + 16 * wm + 4 * g + v;
         if (m < p.M && n < p.N) {
-            float y = acc[v] + bias;
-            if constexpr (EPI == VITHIP_EPI_BIAS_GELU) y = gelu_erf(y);
+            float y;
+            if constexpr (EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN)  // LayerNorm fold, consumer (vit_gemm_common.hpp)
+                y = fold_scale(fold_center(acc[v], p.ln_rows[2 * (size_t)m + 1], p.ln_colsum[n]), p.ln_rows[2 * (size_t)m], bias);
+            else y = acc[v] + bias;
+            if constexpr (EPI == VITHIP_EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_LN) y = gelu_erf(y);
             if constexpr (EPI == VITHIP_EPI_BIAS_RESIDUAL) y += p.R[(size_t)m * p.ldr + n];
             p.C[(size_t)m * p.ldc + n] = y;
         }
@@ -149,6 +152,8 @@ int launch_gemm_f32_latency(hipStream_t stream, GemmParams &p, int epilogue) {
         case VITHIP_EPI_BIAS: hipLaunchKernelGGL(gemm_f32_nt_latency_kernel<VITHIP_EPI_BIAS>, grid, block, 0, stream, p); break;
         case VITHIP_EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_f32_nt_latency_kernel<VITHIP_EPI_BIAS_GELU>, grid, block, 0, stream, p); break;
         case VITHIP_EPI_BIAS_RESIDUAL: hipLaunchKernelGGL(gemm_f32_nt_latency_kernel<VITHIP_EPI_BIAS_RESIDUAL>, grid, block, 0, stream, p); break;
+        case EPI_BIAS_LN: hipLaunchKernelGGL(gemm_f32_nt_latency_kernel<EPI_BIAS_LN>, grid, block, 0, stream, p); break;
+        case EPI_BIAS_GELU_LN: hipLaunchKernelGGL(gemm_f32_nt_latency_kernel<EPI_BIAS_GELU_LN>, grid, block, 0, stream, p); break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());

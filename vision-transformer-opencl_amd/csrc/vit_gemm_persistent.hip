@@ -61,6 +61,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
 
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PLD];
     __shared__ int sk_decision;  // owner: 1 = the helper's piece is there (written by thread 0, read by all after a barrier)
+    // LayerNorm fold, consumer epilogues: (rstd, mean) of the tile's BM rows = 1 KB, copied here when the tile BEGINS by one
+    // global -> LDS instruction of wave 0 (16 bytes per lane), written as inline assembly so that it stays off the compiler's
+    // vmcnt book-keeping: a value fetched at the tile's start and consumed at its end -- in registers or through the
+    // buffer-load-to-LDS builtin alike -- makes the compiler wait for EVERYTHING in flight at the point of use (it cannot count
+    // the restage loads of a run-time number of K-steps in between): a drained staging pipeline once per tile, measured +0.8 us
+    // per tile (fc1 +2 %).  vmcnt retires in order, so "at most 16 outstanding" at the top of the tile's LAST K-step means the
+    // copy, at least three K-steps and 24 loads old by then, has landed; the barrier inside that step publishes it.  Two buffers,
+    // alternating: wave 0 issues the next tile's copy as soon as ITS epilogue is done, while the other waves may still be reading
+    // the finished tile's pairs; a buffer's next writer is two tiles (many barriers) later.  (An unknown younger operation in the
+    // queue only makes the compiler's own counted waits wait for one load more than they need.)
+    constexpr bool FOLD = EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN;
+    __shared__ __attribute__((aligned(16))) f32x2 fold_rows_lds[FOLD ? 2 * BM : 2];
+    static_assert(!FOLD || BM == 128, "one 16-byte lane copy of 64 lanes = 128 rows");
     float *const As0 = lds;
     float *const Bs0 = lds + 2 * BM * PLD;
 
@@ -298,7 +311,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
 
     // ---- compute cursor --------------------------------------------------------------------------
     int seg_c = 0, k_c, kend_c, m0, n0, out_c;
+    [[maybe_unused]] int seg_k0 = 0;  // first K-step of the compute cursor's segment
     float bias_r[TN];
+    FoldOperands<TN> fold{};
+    [[maybe_unused]] int fold_buf = 0;  // which half of fold_rows_lds the compute cursor's tile uses
     auto begin_segment = [&](int i) {
         const Seg g = get_seg(i);
         int tm, tn;
@@ -306,9 +322,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         m0 = tm * BM;
         n0 = tn * BN;
         k_c = g.k0;
+        seg_k0 = g.k0;
         kend_c = g.k1;
         out_c = g.out;
         if (g.out < 0) load_bias(n0, bias_r);  // consumed at the segment's end
+        if constexpr (FOLD) {
+            if (g.out < 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WN + j * 32 + r;
+                    fold.colsum[j] = n < p.N ? p.ln_colsum[n] : 0.0f;
+                }
+                if (wave == 0) {  // the rows' pairs -> LDS (see fold_rows_lds); rows past M read as zero, never stored
+                    const int left = p.M - m0 < BM ? p.M - m0 : BM;
+                    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ln_rows) + (size_t)m0 * 2, 0, left * 8, 0x00020000);
+                    const unsigned dst = (unsigned)(size_t)(fold_rows_lds + fold_buf * BM);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(lane * 16), "s"(rr) : "memory", "m0");
+                }
+                fold.rows = fold_rows_lds + fold_buf * BM;
+                fold_buf ^= 1;
+            }
+        }
         if (SK && g.in >= 0) {
             unpark(g.in);
         } else {
@@ -340,6 +374,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     int cur = 0;
     for (int g = 0; g < steps; ++g) {
         const int k_ahead = k_l * PBK;  // offset of the step the restage loads fetch (step g + 2)
+        if constexpr (FOLD) {
+            if (k_c + 1 == kend_c && out_c < 0) {  // the tile's last step: the copy of its rows' pairs has landed (see fold_rows_lds)
+                if (kend_c - seg_k0 >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (c + 1 < NC && DBG != 4) read_frags(cur, c + 1, (c + 1) & 1);
@@ -372,7 +412,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
             unsigned long long e0 = 0;
             if constexpr (STAMP) e0 = __builtin_amdgcn_s_memtime();
             if (SK && out_c >= 0) park(out_c);
-            else if (DBG != 1 || p.M < 0) epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h);  // (M < 0: never; keeps the MFMAs alive)
+            else if (DBG != 1 || p.M < 0) {  // (M < 0: never; keeps the MFMAs alive)
+                if constexpr (EPI == EPI_RESIDUAL_STATS) epilogue_store_residual_stats<BM, BN, WM, WN>(p, acc, bias_r, m0, n0, wm, wn, r, h);
+                else epilogue_store<BM, BN, WM, WN, EPI, A_DENSE>(p, acc, bias_r, m0, n0, wm, wn, r, h, fold);
+            }
             if constexpr (STAMP) st_epi += __builtin_amdgcn_s_memtime() - e0;
             if (++seg_c < nseg) begin_segment(seg_c);
         }
@@ -434,6 +477,15 @@ int launch_persistent_tile(hipStream_t stream, GemmParams &p, int epilogue, int 
             case VITHIP_EPI_BIAS_RESIDUAL:
                 hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS_RESIDUAL, false, true>), grid, block, 0, stream, p);
                 break;
+            case EPI_BIAS_LN:
+                hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, EPI_BIAS_LN, false, true>), grid, block, 0, stream, p);
+                break;
+            case EPI_BIAS_GELU_LN:
+                hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, EPI_BIAS_GELU_LN, false, true>), grid, block, 0, stream, p);
+                break;
+            case EPI_RESIDUAL_STATS:
+                hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, EPI_RESIDUAL_STATS, false, true>), grid, block, 0, stream, p);
+                break;
             default:
                 return static_cast<int>(hipErrorInvalidValue);
         }
@@ -448,6 +500,15 @@ int launch_persistent_tile(hipStream_t stream, GemmParams &p, int epilogue, int 
             break;
         case VITHIP_EPI_BIAS_RESIDUAL:
             hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, VITHIP_EPI_BIAS_RESIDUAL>), grid, block, 0, stream, p);
+            break;
+        case EPI_BIAS_LN:
+            hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, EPI_BIAS_LN>), grid, block, 0, stream, p);
+            break;
+        case EPI_BIAS_GELU_LN:
+            hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, EPI_BIAS_GELU_LN>), grid, block, 0, stream, p);
+            break;
+        case EPI_RESIDUAL_STATS:
+            hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<BM, BN, WM, WN, EPI_RESIDUAL_STATS>), grid, block, 0, stream, p);
             break;
         default:
             return static_cast<int>(hipErrorInvalidValue);
@@ -508,6 +569,11 @@ int launch_persistent_switchoff(hipStream_t stream, GemmParams &p, int epilogue,
 
 // Entry used by vit_gemm.hip's dispatcher.  Needs at least 4 K steps per tile (K >= 128).
 int launch_persistent(hipStream_t stream, GemmParams &p, int epilogue, int group_m) {
+    // residual GEMM whose caller also wants the row statistics of what it stores: in the epilogue when the columns are whole tiles
+    if (epilogue == VITHIP_EPI_BIAS_RESIDUAL && p.row_partials && p.N % 128 == 0) {
+        epilogue = EPI_RESIDUAL_STATS;
+        p.stats_in_epilogue = 1;
+    }
     return launch_persistent_tile<128, 128, 64, 64>(stream, p, epilogue, group_m);
 }
 

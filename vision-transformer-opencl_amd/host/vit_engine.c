@@ -41,9 +41,12 @@ struct vit_engine {
     size_t wblob_bytes;          /* bytes of it that carry data (the allocation has a read-only tail pad behind) */
     float **w;                   /* device pointer per weight index */
     unsigned short *wblob16;     /* the bf16 section inside wblob (dtype bf16 only) */
-    int fold;                    /* LayerNorm fold active (bf16 engines, vit_engine_options.ln_fold) */
-    unsigned short *wfold16;     /* per layer [gamma1-folded in_proj 3D x D | gamma2-folded fc1 H x D] (bf16) */
+    int fold;                    /* LayerNorm fold active (vit_engine_options.ln_fold) */
+    unsigned short *wfold16;     /* per layer [gamma1-folded in_proj 3D x D | gamma2-folded fc1 H x D] (bf16 engines) */
+    float *wfold32;              /* the same two operands as fp32 products gamma * W (fp32 engines) */
     float *wfoldf;               /* per layer [colsum qkv 3D | bias qkv 3D | colsum fc1 H | bias fc1 H] */
+    float *ln_rows32;            /* fp32 engines: (rstd, mean) per token row [max_batch * tokens][2], then per class row [max_batch][2] */
+    float *ln_part32;            /* ... and the residual GEMMs' scratch for them: [embed_dim / 64][rows][2] per lane (vithip_gemm_args.stats_partials) */
     int lane_cap;                /* most images one lane may hold (32-bit buffer offsets of the fp32 kernels) */
     void *gemm_ws[VIT_MAX_LANES]; /* per lane in use (= per stream): vithip_gemm_args.workspace handles */
     long handover_taken, handover_recomputed;
@@ -252,6 +255,20 @@ int vit_engine_create(vit_engine **out, const vit_config *cfg, const vit_engine_
             HIP_TRY(e, vithip_malloc((void **)&e->wfoldf, L * (6 * D + 2 * H) * sizeof(float)));
         }
     }
+    if (e->opt.dtype == VIT_DTYPE_F32 && e->opt.ln_fold >= 0) {
+        /* fp32 fold: the consumer epilogue exists in every fp32 GEMM kernel; the row statistics kernel wants whole 64-column strips */
+        const int ok = e->cfg.embed_dim % 64 == 0 && e->cfg.embed_dim <= 2048;
+        if (!ok && e->opt.ln_fold > 0) return fail(e, VIT_ERR_ARG, "ln_fold (fp32) needs embed_dim to be a multiple of 64, at most 2048");
+        e->fold = ok;
+        if (e->fold) {
+            const size_t L = (size_t)e->cfg.depth;
+            HIP_TRY(e, vithip_malloc((void **)&e->wfold32, L * (3 * D * D + H * D) * sizeof(float) + WEIGHT_TAIL_PAD));
+            HIP_TRY(e, vithip_memset((char *)e->wfold32 + L * (3 * D * D + H * D) * sizeof(float), 0, WEIGHT_TAIL_PAD, e->stream));
+            HIP_TRY(e, vithip_malloc((void **)&e->wfoldf, L * (6 * D + 2 * H) * sizeof(float)));
+            HIP_TRY(e, vithip_malloc((void **)&e->ln_rows32, (B * T + B) * 2 * sizeof(float)));
+            HIP_TRY(e, vithip_malloc((void **)&e->ln_part32, (D / 64) * B * T * 2 * sizeof(float)));
+        }
+    }
     HIP_TRY(e, vithip_stream_create(&e->copy_stream));
     for (int b = 0; b < 2; ++b) {
         HIP_TRY(e, vithip_malloc((void **)&e->in_stage[b], B * img * sizeof(float)));
@@ -293,6 +310,9 @@ void vit_engine_destroy(vit_engine *e) {
     }
     vithip_free(e->wblob);
     vithip_free(e->wfold16);
+    vithip_free(e->wfold32);
+    vithip_free(e->ln_rows32);
+    vithip_free(e->ln_part32);
     vithip_free(e->wfoldf);
     free(e->w16);
     for (int j = 0; j < VIT_MAX_LANES - 1; ++j) {
@@ -359,8 +379,14 @@ static int fold_ln_weights(vit_engine *e) {
     const size_t D = (size_t)e->cfg.embed_dim, H = (size_t)e->cfg.hidden_dim;
     for (int l = 0; l < e->cfg.depth; ++l) {
         float **lw = e->w + 4 + VIT_WEIGHTS_PER_LAYER * l;
-        unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);
         float *ff = e->wfoldf + (size_t)l * (6 * D + 2 * H);
+        if (e->opt.dtype == VIT_DTYPE_F32) { /* fp32 products gamma * W; sums in double, rounded once */
+            float *f32 = e->wfold32 + (size_t)l * (3 * D * D + H * D);
+            HIP_TRY(e, vithip_ln_fold_weights_f32(e->stream, lw[2], lw[3], lw[0], lw[1], f32, ff, ff + 3 * D, (int)(3 * D), (int)D));
+            HIP_TRY(e, vithip_ln_fold_weights_f32(e->stream, lw[8], lw[9], lw[6], lw[7], f32 + 3 * D * D, ff + 6 * D, ff + 6 * D + H, (int)H, (int)D));
+            continue;
+        }
+        unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);
         /* in_proj: the Q rows also carry the factor of the scores' exponent (the attention kernels are told: _qscaled) */
         HIP_TRY(e, vithip_ln_fold_weights_scaled(e->stream, lw[2], lw[3], lw[0], lw[1], f16, ff, ff + 3 * D, (int)(3 * D), (int)D, (int)D, VITHIP_QSCALE));
         HIP_TRY(e, vithip_ln_fold_weights(e->stream, lw[8], lw[9], lw[6], lw[7], f16 + 3 * D * D, ff + 6 * D, ff + 6 * D + H, (int)H, (int)D));
@@ -487,6 +513,52 @@ static int gemm(vit_engine *e, vithip_stream_t s, int stage, const float *A, int
     return VIT_OK;
 }
 
+/* fp32 consumer of the LayerNorm fold: A = the un-normalised rows x, Wf / bias_f / colsum the folded operands, rows = (rstd,
+ * mean) per row of A (vithip_gemm_args.ln_rows) */
+static int gemm_fold(vit_engine *e, vithip_stream_t s, int stage, const float *A, int lda, const float *Wf, const float *bias_f,
+                     const float *colsum, const float *rows, float *C, int ldc, int M, int N, int K, int epi) {
+    vithip_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.workspace = e->gemm_ws[0];
+    for (int j = 0; j < VIT_MAX_LANES - 1; ++j)
+        if (s == e->aux_stream[j]) a.workspace = e->gemm_ws[j + 1];
+    a.handover_test = e->opt.gemm_handover_test;
+    a.A = A; a.lda = lda; a.W = Wf; a.ldw = K; a.bias = bias_f; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
+    a.tile = e->opt.gemm_tile; a.group_m = 0;
+    a.ln_rows = rows; a.ln_colsum = colsum;
+    HIP_TRY(e, stage_begin(e, s, stage));
+    HIP_TRY(e, vithip_gemm_f32(s, &a));
+    HIP_TRY(e, stage_end(e, s));
+    return VIT_OK;
+}
+/* fp32 residual GEMM in place (x += A . W^T + b) that also leaves the (rstd, mean) of the rows it stored in `rows` WHEN its
+ * kernel can take the sums in its epilogue (the persistent walk: large batches); *took says whether it did -- otherwise the
+ * caller runs the statistics pass (rowstats32), so that small batches keep their launch list and the stage profile its meaning */
+static int gemm_res_stats(vit_engine *e, vithip_stream_t s, int stage, const float *A, int lda, const float *W, const float *bias,
+                          float *x, int ldx, int M, int N, int K, float *rows, float *partials, int *took) {
+    vithip_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.workspace = e->gemm_ws[0];
+    for (int j = 0; j < VIT_MAX_LANES - 1; ++j)
+        if (s == e->aux_stream[j]) a.workspace = e->gemm_ws[j + 1];
+    a.handover_test = e->opt.gemm_handover_test;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.residual = x; a.ldr = ldx; a.C = x; a.ldc = ldx;
+    a.M = M; a.N = N; a.K = K; a.epilogue = VITHIP_EPI_BIAS_RESIDUAL; a.tile = e->opt.gemm_tile;
+    a.stats_out = rows; a.stats_partials = partials;
+    *took = rows != NULL && vithip_gemm_f32_stats_in_epilogue(&a);
+    if (!*took) a.stats_out = a.stats_partials = NULL;
+    HIP_TRY(e, stage_begin(e, s, stage));
+    HIP_TRY(e, vithip_gemm_f32(s, &a));
+    HIP_TRY(e, stage_end(e, s));
+    return VIT_OK;
+}
+static int rowstats32(vit_engine *e, vithip_stream_t s, const float *x, size_t ldx, float *rows, int n_rows, int D) {
+    HIP_TRY(e, stage_begin(e, s, VIT_STAGE_LN));
+    HIP_TRY(e, vithip_rowstats_f32(s, x, ldx, rows, n_rows, D));
+    HIP_TRY(e, stage_end(e, s));
+    return VIT_OK;
+}
+
 static int gemm16(vit_engine *e, vithip_stream_t s, int stage, const unsigned short *A, int lda, const unsigned short *W,
                   const float *bias, const float *res, void *C, int ldc, int M, int N, int K, int epi) {
     vithip_gemm_bf16_args a;
@@ -561,6 +633,7 @@ static int collect_profile(vit_engine *e) {
 typedef struct {
     vithip_stream_t s;
     int off, n; /* first image of the lane inside the chunk, image count */
+    int stats_ready; /* fp32 fold: the residual GEMM in front has left the (rstd, mean) of the lane's token rows (its epilogue took the sums) */
 } vit_lane;
 
 typedef struct {
@@ -666,6 +739,65 @@ static int layer_f32_pruned(chunk_ctx *c, float **lw) {
     }
     LANES
         RUN(gemm(e, LN_.s, VIT_STAGE_FC1, e->y + ROWS(j) * D, D, lw[8], lw[9], NULL, e->hbuf + ROWS(j) * H, H, LN_.n, H, D, VITHIP_EPI_BIAS_GELU));
+    LANES
+        RUN(gemm(e, LN_.s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, H, VITHIP_EPI_BIAS_RESIDUAL));
+    return VIT_OK;
+}
+
+/* ---- fp32 layer with the LayerNorm fold (vit_hip_kernels.h, vithip_gemm_args.ln_rows): in_proj and fc1 read the raw rows x with
+ * the gamma/beta-folded operands (f32 / ff) and the rows' (rstd, mean); each LayerNorm (ViT_seq.c:281, 291) is one pass
+ * that reads x and writes 8 bytes per row.  R32(j) = the pairs of lane j's token rows, C32(j) = of its class rows. ---- */
+#define R32(j) (e->ln_rows32 + ROWS(j) * 2)
+#define C32(j) (e->ln_rows32 + ((size_t)e->opt.max_batch * c->T + (size_t)c->lane[j].off) * 2)
+#define P32(j) (e->ln_part32 + ROWS(j) * (size_t)(c->D / 64) * 2)
+static int layer_f32_folded(chunk_ctx *c, float **lw, const float *f32, const float *ff, int feeds_next) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    int ln2_ready[VIT_MAX_LANES];
+    LANES /* LN1 (ViT_seq.c:281): its statistics, unless the fc2 in front has left them */
+        if (!LN_.stats_ready) RUN(rowstats32(e, LN_.s, e->x + ROWS(j) * D, (size_t)D, R32(j), LN_.n * T, D));
+    LANES /* QKV in_proj (ViT_seq.c:134-147) on LN1(x) */
+        RUN(gemm_fold(e, LN_.s, VIT_STAGE_QKV, e->x + ROWS(j) * D, D, f32, ff + 3 * D, ff, R32(j), e->qkv + ROWS(j) * 3 * D, 3 * D, LN_.n * T, 3 * D, D, VITHIP_EPI_BIAS));
+    LANES { /* scores, softmax, P.V (ViT_seq.c:156-215) -> y */
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_f32(LN_.s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, LN_.n, T, heads));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES /* out_proj + residual (ViT_seq.c:219-227,286-288); the statistics of LN2 (ViT_seq.c:291) on the way when the kernel can */
+        RUN(gemm_res_stats(e, LN_.s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, D, lw[4], lw[5], e->x + ROWS(j) * D, D, LN_.n * T, D, D, R32(j), P32(j), &ln2_ready[j]));
+    LANES
+        if (!ln2_ready[j]) RUN(rowstats32(e, LN_.s, e->x + ROWS(j) * D, (size_t)D, R32(j), LN_.n * T, D));
+    LANES /* fc1 + GELU (ViT_seq.c:258-264) on LN2(x) */
+        RUN(gemm_fold(e, LN_.s, VIT_STAGE_FC1, e->x + ROWS(j) * D, D, f32 + (size_t)3 * D * D, ff + 6 * D + H, ff + 6 * D, R32(j), e->hbuf + ROWS(j) * H, H, LN_.n * T, H, D, VITHIP_EPI_BIAS_GELU));
+    LANES /* fc2 + residual (ViT_seq.c:266,297-299); the statistics of the next layer's LN1 on the way when there is one */
+        RUN(gemm_res_stats(e, LN_.s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D, D, LN_.n * T, D, H,
+                           feeds_next ? R32(j) : NULL, P32(j), &LN_.stats_ready));
+    return VIT_OK;
+}
+
+/* the sequence of layer_f32_pruned in folded form: class rows = rows 0, T, 2T, ... */
+static int layer_f32_folded_pruned(chunk_ctx *c, float **lw, const float *f32, const float *ff) {
+    vit_engine *e = c->e;
+    const int T = c->T, D = c->D, H = c->H, heads = e->cfg.num_heads;
+    LANES
+        if (!LN_.stats_ready) RUN(rowstats32(e, LN_.s, e->x + ROWS(j) * D, (size_t)D, R32(j), LN_.n * T, D));
+    LANES { /* K and V of every token (folded in_proj rows D..3D); Q of the class rows, whose pairs are made compact first */
+        RUN(gemm_fold(e, LN_.s, VIT_STAGE_QKV, e->x + ROWS(j) * D, D, f32 + (size_t)D * D, ff + 3 * D + D, ff + D, R32(j), e->qkv + ROWS(j) * 3 * D + D, 3 * D, LN_.n * T, 2 * D, D, VITHIP_EPI_BIAS));
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_LN));
+        HIP_TRY(e, vithip_gather_rows_f32(LN_.s, R32(j), (size_t)2 * T, C32(j), 2, LN_.n, 2));
+        HIP_TRY(e, stage_end(e, LN_.s));
+        RUN(gemm_fold(e, LN_.s, VIT_STAGE_QKV, e->x + ROWS(j) * D, T * D, f32, ff + 3 * D, ff, C32(j), e->qkv + ROWS(j) * 3 * D, T * 3 * D, LN_.n, D, D, VITHIP_EPI_BIAS));
+    }
+    LANES {
+        HIP_TRY(e, stage_begin(e, LN_.s, VIT_STAGE_ATTN));
+        HIP_TRY(e, vithip_attention_f32_rows(LN_.s, e->qkv + ROWS(j) * 3 * D, e->y + ROWS(j) * D, LN_.n, T, heads, 1));
+        HIP_TRY(e, stage_end(e, LN_.s));
+    }
+    LANES
+        RUN(gemm(e, LN_.s, VIT_STAGE_OUTPROJ, e->y + ROWS(j) * D, T * D, lw[4], lw[5], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, D, VITHIP_EPI_BIAS_RESIDUAL));
+    LANES RUN(rowstats32(e, LN_.s, e->x + ROWS(j) * D, (size_t)T * D, C32(j), LN_.n, D));   /* LN2 of the class rows */
+    LANES
+        RUN(gemm_fold(e, LN_.s, VIT_STAGE_FC1, e->x + ROWS(j) * D, T * D, f32 + (size_t)3 * D * D, ff + 6 * D + H, ff + 6 * D, C32(j), e->hbuf + ROWS(j) * H, H, LN_.n, H, D, VITHIP_EPI_BIAS_GELU));
     LANES
         RUN(gemm(e, LN_.s, VIT_STAGE_FC2, e->hbuf + ROWS(j) * H, H, lw[10], lw[11], e->x + ROWS(j) * D, e->x + ROWS(j) * D, T * D, LN_.n, D, H, VITHIP_EPI_BIAS_RESIDUAL));
     return VIT_OK;
@@ -833,6 +965,7 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
         c->lane[j].off = (int)((long)nb * j / c->L);
         c->lane[j].n = (int)((long)nb * (j + 1) / c->L) - c->lane[j].off;
         c->lane[j].s = j == 0 ? s : e->aux_stream[j - 1];
+        c->lane[j].stats_ready = 0;
     }
     const size_t B = (size_t)e->opt.max_batch, T = (size_t)c->T, D = (size_t)c->D, H = (size_t)c->H;
     c->y16 = (unsigned short *)e->y; c->qkv16 = (unsigned short *)e->qkv; c->h16 = (unsigned short *)e->hbuf;
@@ -853,7 +986,11 @@ static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images
         float **lw = e->w + 4 + VIT_WEIGHTS_PER_LAYER * l;
         unsigned short **lw16 = e->w16 + 4 + VIT_WEIGHTS_PER_LAYER * l;
         const int last_pruned = prune && l == cfg->depth - 1;
-        if (!bf16) {
+        if (!bf16 && e->fold) {
+            const float *f32 = e->wfold32 + (size_t)l * (3 * D * D + H * D);
+            const float *ff = e->wfoldf + (size_t)l * (6 * D + 2 * H);
+            RUN(last_pruned ? layer_f32_folded_pruned(c, lw, f32, ff) : layer_f32_folded(c, lw, f32, ff, l + 1 < cfg->depth));
+        } else if (!bf16) {
             RUN(last_pruned ? layer_f32_pruned(c, lw) : layer_f32(c, lw));
         } else if (e->fold) {
             const unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);

@@ -40,6 +40,17 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpus(timeout: float = 600.0) -> int:
+    """GPUs this node shows, counted in a CHILD interpreter: the launching process stays free of torch and of the HIP runtime
+    (a process that has touched the GPU must not start workers).  -1 when the count could not be taken."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                           timeout=timeout)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else -1
+    except (subprocess.SubprocessError, ValueError, IndexError, OSError):
+        return -1
+
+
 def _pump(stream, sink, prefix: str, keep: Optional[List[str]]) -> None:
     for line in iter(stream.readline, ""):
         if keep is not None:
