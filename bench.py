@@ -52,6 +52,12 @@ STAGE_KERNEL = {  # engine stage -> kernel instantiation that runs it at the met
     "attn": "attention_f32_resident_kernel", "ln": "layernorm_f32_kernel", "embed": "gemm_f32_nt_kernel<A_PATCHES>",
     "softmax": "softmax_top1_f32_kernel",
 }
+# ... and with the LayerNorm fold (fp32 default): the consumer / producer instantiations of the same walk, and
+# what is left of the LayerNorm stage (layer 0's statistics pass + the head's LayerNorm; the finalise launches are inside the
+# residual GEMMs' brackets)
+STAGE_KERNEL_FOLD = dict(STAGE_KERNEL, qkv="gemm_f32_nt_persistent_kernel<EPI_BIAS_LN>", fc1="gemm_f32_nt_persistent_kernel<EPI_BIAS_GELU_LN>",
+                         outproj="gemm_f32_nt_persistent_kernel<EPI_RESIDUAL_STATS>", fc2="gemm_f32_nt_persistent_kernel<EPI_RESIDUAL_STATS>",
+                         ln="rowstats_f32_kernel")
 
 
 WEIGHT_SEED = 1234      # synthetic weights of every configuration (the golden fixtures were written with it)
@@ -203,14 +209,14 @@ def stage_macs(cfg, batch):
     }
 
 
-def dominant_kernel(times, cfg, B, dtype, kernel_steps, saved=None):
+def dominant_kernel(times, cfg, B, dtype, kernel_steps, saved=None, fold=False):
     """Per-kernel launch time and algorithmic FLOPs from the engine's stage brackets (one lane, every launch alone on the
     GPU) -> (name, record, average launch ms, achieved TFLOP/s) of the kernel with the most time, + all-GEMM ms and FLOPs."""
     saved = saved or {}
     macs = stage_macs(cfg, B)
     per_kernel = {}
     for stage, rec in times["stages"].items():
-        k = STAGE_KERNEL[stage]
+        k = (STAGE_KERNEL_FOLD if fold and dtype != "bf16" else STAGE_KERNEL)[stage]
         if dtype == "bf16" and stage == "embed":
             k = "gemm_bf16_pp_kernel<F32_EMBED>"
         if dtype == "bf16" and stage == "attn":
@@ -347,7 +353,7 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true",
                     help="vit_engine_options.use_graph: replay the forward as one hipGraph (needs --lanes 1; small batches)")
     ap.add_argument("--ln-fold", type=int, default=0, choices=(-1, 0, 1),
-                    help="bf16: fold the encoder LayerNorms into the GEMMs either side (0 auto = on, -1 off: LayerNorm kernels)")
+                    help="fold the encoder LayerNorms into the GEMMs either side (0 auto = on, -1 off: a LayerNorm kernel each, the reference's operation order)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="tuning: vithip_gemm_args.tile of every fp32 GEMM (0 auto; 6..12, include/vit_hip_kernels.h)")
     ap.add_argument("--config", type=int, default=0, choices=(0, 1, 2, 3, 4),
                     help="BASELINE.json configs[i] preset: 1 = fp32 batch 256 (the metric, the default), 2 = bf16 batch 2048, "
@@ -522,7 +528,7 @@ def main() -> None:
 
     # ---- roofline of the dominant kernel (per-launch, from the stage brackets) -------------------
     peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-    dom_name, dom, avg_ms, achieved, gemm_ms, gemm_flop = dominant_kernel(times, cfg, B, args.dtype, kernel_steps, saved)
+    dom_name, dom, avg_ms, achieved, gemm_ms, gemm_flop = dominant_kernel(times, cfg, B, args.dtype, kernel_steps, saved, fold=args.ln_fold >= 0 and cfg.embed_dim % 64 == 0)
     tag = profile_tag(args.dtype, args.model)
     traffic, traffic_src = pmc_traffic(dom_name, tag, B)
     busy, clock = pmc_mfma(dom_name, tag, B)

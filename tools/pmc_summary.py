@@ -48,7 +48,7 @@ def short_name(name):
     return name.strip()
 
 
-EPI = {"0": "EPI_BIAS", "1": "EPI_BIAS_GELU", "2": "EPI_BIAS_RESIDUAL"}
+EPI = {"0": "EPI_BIAS", "1": "EPI_BIAS_GELU", "2": "EPI_BIAS_RESIDUAL", "3": "EPI_BIAS_LN", "4": "EPI_BIAS_GELU_LN", "5": "EPI_RESIDUAL_STATS"}
 EPI16 = {"0": "BF16", "1": "BF16_GELU", "2": "F32_RESIDUAL", "3": "F32_EMBED"}
 
 

@@ -81,7 +81,7 @@ void initialize_hip(void) {
     /* concurrent sub-batches (bit-identical): fp32 1 -- its GEMMs balance their own tails and assume their workgroups resident;
      * bf16 2 -- the HBM-bound LayerNorm / residual kernels of one lane overlap the other's GEMMs (+6 %) */
     opt.lanes = env_int("VIT_HIP_LANES", opt.dtype == VIT_DTYPE_BF16 ? 2 : 1);
-    opt.ln_fold = env_int("VIT_HIP_LN_FOLD", 0); /* bf16 only: 0 auto (LayerNorms folded into the GEMMs), -1 LayerNorm kernels */
+    opt.ln_fold = env_int("VIT_HIP_LN_FOLD", 0); /* 0 auto (encoder LayerNorms folded into the GEMMs either side), -1 a LayerNorm kernel each */
     vit_config cfg = vit_config_b16(); /* the reference's compile-time model (ViT_opencl.c:12-23) */
     int n = parse_devices(g_vit.device);
     if (n == 0) {
