@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
         const int n = n0 + wn * WN + j * 32 + r;
         bias_r[j] = n < p.N ? p.bias[n] : 0.0f;
     }
-    FoldOperands<TN> fold{};  // LayerNorm fold (consumer): the folded weight's column sums beside the bias, the rows' pairs from memory
+    FoldOperands<TN, TM> fold{};  // LayerNorm fold (consumer): the folded weight's column sums and the lane's rows' pairs beside the bias
     if constexpr (EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
             fold.colsum[j] = n < p.N ? p.ln_colsum[n] : 0.0f;
         }
         fold.rows = reinterpret_cast<const f32x2 *>(p.ln_rows) + m0;
+        fold_preload(fold, p.ln_rows, p.M, m0 + wm * WM, r, h);
     }
 
     const int nk = p.K / BK;

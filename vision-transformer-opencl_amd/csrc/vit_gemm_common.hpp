@@ -171,11 +171,30 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
 // tiles take a branch-free path, and the residual / pos_emb operands of one accumulator are loaded
 // in batches before their stores.
 // LayerNorm fold, consumer side (EPI_BIAS_LN / EPI_BIAS_GELU_LN): what the epilogue needs besides the bias
-template <int TN>
+template <int TN, int TM = 1>
 struct FoldOperands {
     float colsum[TN];   // column sums of the folded weight at this lane's columns (fetched with the bias, long before)
     const f32x2 *rows;  // (rstd, mean) of the tile's rows m0, m0 + 1, ...: p.ln_rows + 2 m0, or the persistent walk's LDS copy of them
+    // one tile per workgroup: the lane's own values, fetched with the bias when the kernel starts (read from memory in the
+    // epilogue they are 17 exposed loads per 32-row block: +2-3 % on the small-batch launches); `preloaded` says so
+    float rstd[TM][16], mean[TM];
+    bool preloaded;
 };
+// the lane's (rstd of its 16 rows, mean of row r) per 32-row block, for FoldOperands::rstd / mean
+template <int TN, int TM>
+__device__ __forceinline__ void fold_preload(FoldOperands<TN, TM> &fold, const float *ln_rows, int M, int m_tile, int r, int h) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mr = m_tile + i * 32 + r;
+        fold.mean[i] = ln_rows[2 * (size_t)(mr < M ? mr : M - 1) + 1];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int m = m_tile + i * 32 + 4 * h + (v & 3) + 8 * (v >> 2);
+            fold.rstd[i][v] = ln_rows[2 * (size_t)(m < M ? m : M - 1)];
+        }
+    }
+    fold.preloaded = true;
+}
 // The fold's value, the same two fused multiply-adds in every kernel:
 //     acc' = fma(-mean, colsum, acc)     x . (gamma W)^T - mean * colsum(gamma W) = (x - mean) . (gamma W)^T
 //     y    = fma(rstd, acc', bias_f)
@@ -189,7 +208,7 @@ __device__ __forceinline__ float fold_scale(float centered, float rstd, float bi
 template <int BM, int BN, int WM, int WN, int EPI, int AMODE>
 __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16 (&acc)[WM / 32][WN / 32],
                                                const float (&bias_r)[WN / 32], int m0, int n0, int wm, int wn,
-                                               int r, int h, const FoldOperands<WN / 32> &fold = FoldOperands<WN / 32>{}) {
+                                               int r, int h, const FoldOperands<WN / 32, WM / 32> &fold = FoldOperands<WN / 32, WM / 32>{}) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr bool FOLD = EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN;
     constexpr bool GELU = EPI == VITHIP_EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_LN;
@@ -207,7 +226,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int lr0 = wm * WM + i * 32;
-                const float mean = fold.rows[lr0 + r].y;
+                const float mean = fold.preloaded ? fold.mean[i] : fold.rows[lr0 + r].y;
                 const float a_op = h == 0 ? -mean : 0.0f;
                 f32x16 centered[TN];
 #pragma unroll
@@ -217,7 +236,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
                 for (int g = 0; g < 4; ++g) {
                     const int lr = lr0 + 4 * h + 8 * g;  // tile-local row of registers 4g .. 4g + 3
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) row_rstd[4 * g + e] = fold.rows[lr + e].x;
+                    for (int e = 0; e < 4; ++e) row_rstd[4 * g + e] = fold.preloaded ? fold.rstd[i][4 * g + e] : fold.rows[lr + e].x;
                 }
                 const int mb = m0 + lr0 + 4 * h;  // row of register 0
 #pragma unroll

@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_latency_kernel(const GemmPara
 
     const int n = n0 + 16 * wn + n16;
     const float bias = n < p.N ? p.bias[n] : 0.0f;
+    // LayerNorm fold (consumer): the column sum and the lane's four rows' (rstd, mean), fetched now like the bias -- this kernel's
+    // time IS its dependent chain, a load in the epilogue would be on it
+    [[maybe_unused]] float colsum = 0.0f;
+    [[maybe_unused]] f32x2 rowpair[4] = {};
+    if constexpr (EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN) {
+        colsum = n < p.N ? p.ln_colsum[n] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int m = m0 + 16 * wm + 4 * g + v;
+            rowpair[v] = reinterpret_cast<const f32x2 *>(p.ln_rows)[m < p.M ? m : p.M - 1];
+        }
+    }
     // fragment elements of this lane inside a chunk of eight k: k = {0, 4, 1, 5}[g] for the chunk's first MFMA, + 2 for its
     // second; in LDS: word 2c + (g & 1) of the row, elements rotated by (row >> 2) & 3 = (n16 >> 2) & 3
     const int pos1 = ((g >> 1) + (n16 >> 2)) & 3, pos2 = (pos1 + 2) & 3;
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_latency_kernel(const GemmPara
         if (m < p.M && n < p.N) {
             float y;
             if constexpr (EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN)  // LayerNorm fold, consumer (vit_gemm_common.hpp)
-                y = fold_scale(fold_center(acc[v], p.ln_rows[2 * (size_t)m + 1], p.ln_colsum[n]), p.ln_rows[2 * (size_t)m], bias);
+                y = fold_scale(fold_center(acc[v], rowpair[v].y, colsum), rowpair[v].x, bias);
             else y = acc[v] + bias;
             if constexpr (EPI == VITHIP_EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_LN) y = gelu_erf(y);
             if constexpr (EPI == VITHIP_EPI_BIAS_RESIDUAL) y += p.R[(size_t)m * p.ldr + n];

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
     int seg_c = 0, k_c, kend_c, m0, n0, out_c;
     [[maybe_unused]] int seg_k0 = 0;  // first K-step of the compute cursor's segment
     float bias_r[TN];
-    FoldOperands<TN> fold{};
+    FoldOperands<TN, TM> fold{};
     [[maybe_unused]] int fold_buf = 0;  // which half of fold_rows_lds the compute cursor's tile uses
     auto begin_segment = [&](int i) {
         const Seg g = get_seg(i);
