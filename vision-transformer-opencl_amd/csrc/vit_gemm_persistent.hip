@@ -307,6 +307,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * q4 + e] = v[e];
                 }
+        // The piece has LANDED before the K loop goes on -- said with the builtin, which the compiler's wait-count pass reads
+        // (inline assembly it does not): accumulators "possibly still in flight" at the loop header made it put vmcnt(12) / (8) /
+        // (5) / (1) in front of the first four MFMAs of EVERY K-step of the helper-piece instantiations, i.e. it drained the staging
+        // queue at the top of each step where the plain walk only has its eight counted vmcnt(7).  Once per owner workgroup.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
     };
 
     // ---- compute cursor --------------------------------------------------------------------------
