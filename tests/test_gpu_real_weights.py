@@ -95,6 +95,38 @@ def test_out_proj_residual_and_ln2_on_real_weights(g):
         assert (err <= 2.0 ** -8 * np.abs(ref) + 7.0 * sigma + carried + 1e-4).all(), int(l)
 
 
+def test_fp32_layernorm_fold_on_real_gamma_beta_and_massive_channels(g):
+    """The fp32 fold where its cancellation is hardest: the real out_proj in front (residual rows with the
+    reference's "massive" channels, x30 the typical magnitude), the row statistics from the GEMM's own epilogue, the real ln_2
+    gamma / beta folded into an fc1-shaped weight behind, x . (gamma W)^T - mean * colsum taken on the raw rows.  Reference: the
+    compiled reference's own LayerNorm rows times that weight in float64; bar: the fp32 operators' 2e-5 x magnitude."""
+    seed, rows = int(g["seed"]), list(g["rows"])
+    for l in g["outproj_layers"]:
+        a, xres = activation_inputs(seed, int(l))
+        ow, ob = g[f"outproj_w_{l}"], g[f"outproj_b_{l}"]
+        want_z = g[f"ln2_rows_{l}"]
+        st9, st0 = {}, {}
+        r = B.gemm(a, ow, ob, residual=xres, epilogue=B.EPI_BIAS_RESIDUAL, tile=9, row_stats=st9)      # statistics in the epilogue
+        r0 = B.gemm(a, ow, ob, residual=xres, epilogue=B.EPI_BIAS_RESIDUAL, row_stats=st0)             # ... from the statistics kernel
+        assert st9["in_epilogue"] == 1 and st0["in_epilogue"] == 0
+        assert np.array_equal(r, r0) and np.array_equal(st9["rows"], st0["rows"])
+        x64 = r.astype(np.float64)
+        assert np.abs(st9["rows"][:, 1] - x64.mean(1)).max() <= 2e-6 * mag(x64.mean(1)) + 1e-7
+        assert np.abs(st9["rows"][:, 0] * np.sqrt(x64.var(1) + 1e-6) - 1.0).max() <= 1e-5
+        W1 = synth.uniform(seed, 900 + int(l), 512 * r.shape[1], -0.05, 0.05).reshape(512, r.shape[1])
+        b1 = synth.uniform(seed, 950 + int(l), 512, -0.1, 0.1)
+        Wf, cs, bf = B.ln_fold_weights_f32(W1, b1, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"])
+        ref = want_z.astype(np.float64) @ W1.astype(np.float64).T + b1
+        for tile in (0, 9):
+            got = B.gemm(r, Wf, bf, epilogue=B.EPI_BIAS, tile=tile, ln=(st9["rows"], cs))[rows]
+            err = float(np.abs(got - ref).max())
+            print(f"layer {int(l)} tile {tile}: folded LN2 + fc1-shaped fp32 GEMM on real gamma/beta: max |d| = {err:.3g} of {mag(ref):.2f} "
+                  f"(row max |x| {mag(r[rows]):.1f}, mean up to {float(np.abs(st9['rows'][rows, 1]).max()):.3f})")
+            assert err <= 2e-5 * mag(ref), (int(l), tile)
+        plain = B.gemm(B.layernorm(r, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"]), W1, b1, epilogue=B.EPI_BIAS)[rows]   # the unfolded order, for scale
+        print(f"layer {int(l)}: LayerNorm kernel + plain GEMM: max |d| = {float(np.abs(plain - ref).max()):.3g}")
+
+
 def test_final_ln_and_head_on_real_weights(g):
     seed = int(g["seed"])
     xf = head_input(seed)[:8]
