@@ -175,8 +175,8 @@ template <int TN, int TM = 1>
 struct FoldOperands {
     float colsum[TN];   // column sums of the folded weight at this lane's columns (fetched with the bias, long before)
     const f32x2 *rows;  // (rstd, mean) of the tile's rows m0, m0 + 1, ...: p.ln_rows + 2 m0, or the persistent walk's LDS copy of them
-    // one tile per workgroup: the lane's own values, fetched with the bias when the kernel starts (read from memory in the
-    // epilogue they are 17 exposed loads per 32-row block: +2-3 % on the small-batch launches); `preloaded` says so
+    // one tile per workgroup: the lane's own values, fetched with the bias when the kernel starts -- the bias's rule: no load
+    // pending in the epilogue (17 per 32-row block otherwise); `preloaded` says so
     float rstd[TM][16], mean[TM];
     bool preloaded;
 };
