@@ -304,7 +304,7 @@ __global__ void cls_rows_bf16path_kernel(const float *cls, const float *pos, flo
 bool aligned16(const void *ptr) { return (reinterpret_cast<size_t>(ptr) & 15) == 0; }
 // The kernel variant is a per-call field of vithip_gemm_bf16_args; the product library has no mutable process-wide state.  The probe build (-DVIT_PROBES) adds process-wide overrides and instrumented kernels.
 #ifdef VIT_PROBES
-int g_variant = 0;  // 0 none, 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong, 4 event-log ping-pong
+int g_variant = 0;  // 0 none, 1 two-stage kernel, 2 ping-pong, 3 stamped ping-pong, 4 event-log ping-pong, 5 four-wave experiment (vit_gemm_bf16_w4.hip)
 unsigned long long *g_dbg = nullptr;
 int g_max_wgs = 0;    // event-log build: cap on persistent workgroups (0 = one per CU)
 int g_group16 = 0;    // tile rows per L2 group of the walk (0 = the launcher's choice)
@@ -327,7 +327,7 @@ int vithip_f32_to_bf16(vithip_stream_t stream, const float *src, unsigned short 
 
 #ifdef VIT_PROBES
 int vithip_gemm_bf16_set_variant(int variant) {
-    if (variant < 0 || variant > 4) return static_cast<int>(hipErrorInvalidValue);
+    if (variant < 0 || variant > 5) return static_cast<int>(hipErrorInvalidValue);
     g_variant = variant;
     return 0;
 }
@@ -447,6 +447,8 @@ int vithip_gemm_bf16(vithip_stream_t stream, const vithip_gemm_bf16_args *a) {
     // operands addressable through 32-bit buffer offsets inside one tile (always true: 256 rows)
 #ifdef VIT_PROBES
     if (a->epilogue >= 201 && a->epilogue <= 204) return vitgemm::launch_gemm_bf16_pp(s, p, a->epilogue, g_cus);  // timing probes
+    if ((g_variant == 5 && a->epilogue != VITHIP_BF16_EPI_F32_RESIDUAL && !ln_consumer) || (a->epilogue >= 501 && a->epilogue <= 505))
+        return vitgemm::launch_gemm_bf16_w4(s, p, a->epilogue, g_cus);  // four-wave experiment
 #endif
     const bool pp_ok = p.K >= 2 * TBK && a->epilogue >= 0 && a->epilogue <= VITHIP_BF16_EPI_F32_RESIDUAL &&
                        (size_t)p.lda * 2 * 256 < (1u << 31) && (size_t)p.ldw * 2 * 256 < (1u << 31);
