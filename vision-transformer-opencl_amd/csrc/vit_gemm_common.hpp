@@ -212,6 +212,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr bool FOLD = EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN;
     constexpr bool GELU = EPI == VITHIP_EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_LN;
+    constexpr int ST_NT = 2;  // cache policy of the bias / GELU stores: non-temporal (qkv and the hidden layer are read by the NEXT launch)
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);  // workgroup-uniform
     if (interior) {
         if constexpr (FOLD) {
@@ -252,7 +253,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             const int v = half * 8 + q;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[q]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[q]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, ST_NT);
                         }
                     }
                 }
@@ -314,7 +315,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const int v = half * 8 + q;
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[q]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[q]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, ST_NT);
                             }
                         }
                     }
