@@ -213,6 +213,25 @@ def test_gemm_layernorm_fold_persistent_walk_with_helper_pieces():
         assert np.array_equal(B.gemm(x, Wf, bias_f, epilogue=epi, tile=9, ln=(rows, colsum)), ref), epi
 
 
+@pytest.mark.parametrize("K", [64, 128, 192])
+def test_gemm_layernorm_fold_persistent_walk_short_tiles(K):
+    """The persistent consumer proves its copy of the rows' pairs landed by counting: "at most 16 loads outstanding" at the top of a
+    tile's last K-step -- true once three steps' loads are behind the copy, so tiles of fewer than four K-steps (K = 64: two, K = 96:
+    three) wait for everything instead.  Both branches, many tiles per workgroup (1,200 tiles on 512), both epilogues."""
+    M, N = 128 * 75 + 9, 2048
+    x = (u(90, (M, K), 2.0) + u(91, (1, K), 1.0)).astype(np.float32)
+    gamma, beta = (1.0 + u(92, (K,), 0.5)).astype(np.float32), u(93, (K,), 0.5)
+    W, b = u(94, (N, K), 0.05), u(95, (N,), 0.1)
+    Wf, colsum, bias_f = B.ln_fold_weights_f32(W, b, gamma, beta)
+    rows = B.rowstats_f32(x)
+    want = B.gemm(B.layernorm(x, gamma, beta), W, b, epilogue=B.EPI_BIAS, tile=10)
+    for epi in (B.EPI_BIAS, B.EPI_BIAS_GELU):
+        ref = B.gemm(x, Wf, bias_f, epilogue=epi, tile=10, ln=(rows, colsum))
+        assert np.array_equal(B.gemm(x, Wf, bias_f, epilogue=epi, tile=9, ln=(rows, colsum)), ref), epi
+        assert np.array_equal(B.gemm(x, Wf, bias_f, epilogue=epi, tile=9, workspace=True, ln=(rows, colsum)), ref), epi
+    assert float(np.abs(B.gemm(x, Wf, bias_f, epilogue=B.EPI_BIAS, tile=9, ln=(rows, colsum)) - want).max()) <= 2e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(128 * 49 + 57, 768, 768), (128 * 40, 1024, 256), (128 * 171, 768, 128), (300, 768, 128), (128 * 30, 192, 128)])
 def test_gemm_residual_row_statistics_in_the_epilogue(M, N, K):
     """vithip_gemm_args.stats_out: (rstd, mean) of the rows a residual GEMM stores.  The persistent walk takes the sums in
