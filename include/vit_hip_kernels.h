@@ -115,6 +115,8 @@ typedef struct {
      *     fmaf(rstd, fmaf(-mean, colsum, acc), bias) = LayerNorm(x) . W^T + b                 (ViT_seq.c:103-121 is the LayerNorm)
      * with the same two roundings in every kernel (the 32x32 kernels take the inner one as a rank-1 matrix instruction, four per
      * wave and tile: csrc/vit_gemm_common.hpp), so that the tile shapes stay bit-identical to each other.  The
+     * (Rows of near-zero variance: the cancellation error of the inner term is scaled by rstd, up to 1e3 there, where
+     * LayerNorm-then-GEMM gives exact zeros; real residual rows have rstd of order 1.)  The
      * normalised activations never exist in memory: the pass that wrote them (read x, write y: 310 MB at batch 256, 24 times per
      * ViT-B/16 forward) becomes a pass that reads x and writes 8 bytes per row. */
     const float *ln_rows, *ln_colsum;
