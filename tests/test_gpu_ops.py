@@ -213,11 +213,12 @@ def test_gemm_layernorm_fold_persistent_walk_with_helper_pieces():
         assert np.array_equal(B.gemm(x, Wf, bias_f, epilogue=epi, tile=9, ln=(rows, colsum)), ref), epi
 
 
-@pytest.mark.parametrize("K", [64, 128, 192])
+@pytest.mark.parametrize("K", [64, 96, 128, 160, 192])
 def test_gemm_layernorm_fold_persistent_walk_short_tiles(K):
-    """The persistent consumer proves its copy of the rows' pairs landed by counting: "at most 16 loads outstanding" at the top of a
-    tile's last K-step -- true once three steps' loads are behind the copy, so tiles of fewer than four K-steps (K = 64: two, K = 96:
-    three) wait for everything instead.  Both branches, many tiles per workgroup (1,200 tiles on 512), both epilogues."""
+    """The persistent consumer proves its copy of the rows' pairs landed by counting: "at most 2 * NS = 16 loads outstanding" at the top
+    of a tile's last K-step -- true once three steps' loads are behind the copy, so tiles of fewer than four K-steps (K = 64: two,
+    K = 96: three) wait for everything instead; K = 128 is the shortest tile on the counted branch, K = 160 / 192 five and six steps.
+    Both branches, odd and even step counts, many tiles per workgroup (1,200 tiles on 512), both epilogues."""
     M, N = 128 * 75 + 9, 2048
     x = (u(90, (M, K), 2.0) + u(91, (1, K), 1.0)).astype(np.float32)
     gamma, beta = (1.0 + u(92, (K,), 0.5)).astype(np.float32), u(93, (K,), 0.5)

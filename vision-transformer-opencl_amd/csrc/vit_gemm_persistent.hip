@@ -381,7 +381,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
         const int k_ahead = k_l * PBK;  // offset of the step the restage loads fetch (step g + 2)
         if constexpr (FOLD) {
             if (k_c + 1 == kend_c && out_c < 0) {  // the tile's last step: the copy of its rows' pairs has landed (see fold_rows_lds)
-                if (kend_c - seg_k0 >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                // vmcnt retires in order: once at most FOLD_WAIT = 2 * NS operations are outstanding, everything older than the
+                // restage loads of the last two K-steps is done.  The copy was issued before this tile's first restage load, and a
+                // tile of FOLD_MIN_STEPS steps has issued (FOLD_MIN_STEPS - 1) * NS >= FOLD_WAIT + NS of them by now.
+                constexpr int FOLD_WAIT = 2 * NS, FOLD_MIN_STEPS = 4;
+                static_assert(FOLD_WAIT <= 63, "vmcnt is a 6-bit count on gfx950");
+                static_assert((FOLD_MIN_STEPS - 1) * NS >= FOLD_WAIT + NS, "the copy must be older than the loads the wait leaves in flight");
+                if (kend_c - seg_k0 >= FOLD_MIN_STEPS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FOLD_WAIT) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
