@@ -1,5 +1,5 @@
 """The rank launcher bench.py uses for `--gpus N` (vision-transformer-opencl_amd/launch.py), driven HIP-free:
-world size 2, gloo, CPU oracle as the forward (tests/workers/dp_cpu_worker.py)."""
+world size 2 and 8, gloo, CPU oracle as the forward (tests/workers/dp_cpu_worker.py)."""
 import importlib
 import io
 import json
@@ -33,6 +33,28 @@ def test_launcher_runs_two_gloo_ranks_and_relays_rank0(n_images, oracle):
     assert rec["n_local"] == pkg.dp.shard_range(n_images, 0, 2)[1]
     assert rec["labels"] == full.argmax(1).tolist()               # every image's top-1 reached rank 0, in image order
     assert np.array_equal(np.asarray(rec["probs"], np.float32), full.max(1))
+
+
+def test_launcher_walks_the_eight_rank_path_with_a_ragged_split(oracle):
+    """BASELINE.json configs[3] runs one rank per GPU on an 8-GPU node: the same launcher, sharding and gather at their real rank
+    count (gloo, CPU oracle as the forward): 21 images over 8 ranks (rank r owns [21 r / 8, 21 (r + 1) / 8): 2,3,2,3,3,2,3,3), every image's top-1 on rank 0 in image
+    order, and dp.verify_gather -- the check bench.py runs on its RCCL gather -- right as it stands and wrong on every rank when
+    rank 5's copy of one slot is corrupted (the verdict is all-reduced, so rank 0's line carries it)."""
+    pkg = importlib.import_module("vision-transformer-opencl_amd")
+    n_images, world = 21, 8
+    assert [pkg.dp.shard_range(n_images, r, world)[1] - pkg.dp.shard_range(n_images, r, world)[0] for r in range(world)] == [2, 3, 2, 3, 3, 2, 3, 3]
+    rc, out = pkg.launch.launch_ranks(WORKER, [str(n_images), "-1", "5"], world, timeout=600, relay_stdout=io.StringIO())
+    assert rc == 0, out
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    rec = json.loads(lines[0])
+    from conftest import oracle_config
+    cfg = pkg.VIT_TINY
+    full = oracle.forward(oracle_config(cfg), pkg.synth.make_images(cfg, n_images, 6), pkg.synth.make_weights(cfg, 5))
+    assert rec["world"] == world and rec["n_local"] == 2
+    assert rec["labels"] == full.argmax(1).tolist()
+    assert np.array_equal(np.asarray(rec["probs"], np.float32), full.max(1))
+    assert rec["verify"] == [True, False]
 
 
 def test_launcher_reports_a_failed_rank_and_stops_the_rest():

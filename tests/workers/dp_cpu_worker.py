@@ -3,7 +3,8 @@
 Same skeleton as a GPU rank (launch.init_process_group -> forward of this rank's shard -> dp gather -> rank 0
 prints ONE JSON line), with gloo instead of nccl and the CPU oracle instead of the HIP engine (this file lives
 under tests/, the only place besides smoke() and bench.py's cpu_baseline that may use oracle/).
-argv: n_images [fail_rank]
+argv: n_images [fail_rank [corrupt_rank]]   (corrupt_rank >= 0: also run dp.verify_gather on a clean gather and on one whose copy on
+      that rank has one slot changed; the all-reduced verdicts go into rank 0's line)
 """
 import importlib
 import json
@@ -17,6 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     n_images = int(sys.argv[1])
     fail_rank = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+    corrupt_rank = int(sys.argv[3]) if len(sys.argv) > 3 else -1
     pkg = importlib.import_module("vision-transformer-opencl_amd")
     assert "vision-transformer-opencl_amd.binding" not in sys.modules  # the launcher path must not need the HIP library
     rank, local, world = pkg.launch.init_process_group("gloo")
@@ -30,12 +32,21 @@ def main():
     W = pkg.synth.make_weights(cfg, 5)
     imgs = pkg.synth.make_images(cfg, n_images, 6)
     local_probs, labels, probs = pkg.dp.forward_sharded(lambda x: po.forward(ocfg, x, W), imgs, rank, world)
+    verify = None
+    if corrupt_rank >= 0:
+        import torch
+        packed = pkg.dp.pack_top1(torch.arange(3, dtype=torch.int32) + 10 * rank, torch.full((3,), 0.125 * (rank + 1)))
+        gathered = pkg.dp.gather_packed(packed)
+        bad = gathered.clone()
+        if rank == corrupt_rank:
+            bad[(corrupt_rank + 3) % world, 1, 0] += 1     # this rank's copy of ANOTHER rank's slot
+        verify = [bool(pkg.dp.verify_gather(packed, gathered)), bool(pkg.dp.verify_gather(packed, bad))]
     dist.barrier()
     if rank != 0:
         print(f"rank {rank} done")       # must NOT reach the parent's stdout
     else:
         print(json.dumps({"world": world, "labels": labels.tolist(), "probs": [float(p) for p in probs],
-                          "n_local": int(local_probs.shape[0])}))
+                          "n_local": int(local_probs.shape[0]), "verify": verify}))
     dist.destroy_process_group()
 
 
