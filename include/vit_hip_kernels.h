@@ -98,7 +98,8 @@ typedef struct {
      * tile: 0 = auto (persistent walk of 128x128 tiles for problems of many tiles, 128x64 / 64x64 / 32x32 tiles as the problem
      *   shrinks); one software-pipelined tile per workgroup: 10 = 128x128, 6 = 128x128 with K step 16, 7 = 256x128, 8 = 128x64,
      *   11 = 64x64; 12 = 32x32 on 16x16x4 MFMA (K % 128 == 0); 9 = persistent 128x128.  All of them give the same bits.
-     * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default 8; 1 = plain N-fastest order). */
+     * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default: plain N-fastest order when N is at most 8 tiles of
+     *   128 wide, groups of 4 tile rows beyond that; 1 = plain N-fastest order). */
     int tile, group_m;
     /* optional scratch: the HANDLE made by vithip_gemm_f32_workspace_create() on the device the launch runs on (one per
      * stream: launches that share it must be ordered).  With it, large problems whose tile count is not a multiple of the
@@ -114,10 +115,10 @@ typedef struct {
      * per row of A (vithip_rowstats_f32), ln_colsum [N]; the epilogue computes
      *     fmaf(rstd, fmaf(-mean, colsum, acc), bias) = LayerNorm(x) . W^T + b                 (ViT_seq.c:103-121 is the LayerNorm)
      * with the same two roundings in every kernel (the 32x32 kernels take the inner one as a rank-1 matrix instruction, four per
-     * wave and tile: csrc/vit_gemm_common.hpp), so that the tile shapes stay bit-identical to each other.  The
+     * wave and tile: csrc/vit_gemm_common.hpp), so that the tile shapes stay bit-identical to each other.
      * (Rows of near-zero variance: the cancellation error of the inner term is scaled by rstd, up to 1e3 there, where
-     * LayerNorm-then-GEMM gives exact zeros; real residual rows have rstd of order 1.)  The
-     * normalised activations never exist in memory: the pass that wrote them (read x, write y: 310 MB at batch 256, 24 times per
+     * LayerNorm-then-GEMM gives exact zeros; real residual rows have rstd of order 1.  Measured, not asserted away:
+     * tests/test_gpu_lnfold.py::test_fp32_fold_on_near_constant_rows_stays_inside_its_stated_bound.)  The normalised activations never exist in memory: the pass that wrote them (read x, write y: 310 MB at batch 256, 24 times per
      * ViT-B/16 forward) becomes a pass that reads x and writes 8 bytes per row. */
     const float *ln_rows, *ln_colsum;
     /* ... and the producer side (NULL = off; EPI_BIAS_RESIDUAL only, N % 64 == 0, N <= 2048): stats_out [M][2] receives (rstd,

@@ -128,6 +128,8 @@ def test_c_caller_gathers_top1_over_rccl(tmp_path):
     own records and those against the probabilities.  One device here (a communicator of size 1); every device of the node too
     when it has several."""
     import ctypes as C
+    if not os.path.exists(os.path.join(PKG, "libvit_mi355x_dp.so")):
+        pytest.skip("libvit_mi355x_dp.so not built on this box (no RCCL)")
     exe = tmp_path / "dp_caller"
     cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
            os.path.join(ROOT, "tests", "dropin", "dp_caller.c"), "-o", str(exe), f"-L{PKG}", "-lvit_mi355x", "-lvit_mi355x_dp",

@@ -97,3 +97,34 @@ def test_fold_arguments_are_validated():
         B.gemm_bf16(Ab, Wb, b, epilogue=B.BF16_EPI_BF16, ln_rows=rs)
     with pytest.raises(RuntimeError):      # the two-stage kernel has no fold
         B.gemm_bf16(Ab, Wb, b, epilogue=B.BF16_EPI_BF16, ln_rows=rs, ln_colsum=cs, variant=1)
+
+
+def test_fp32_fold_on_near_constant_rows_stays_inside_its_stated_bound():
+    """include/vit_hip_kernels.h (ln_rows): the fp32 fold computes rstd * (x . Wf^T - mean * colsum) + b', so on a row of near-zero
+    variance the cancellation error of the bracket is scaled by rstd (at most 1 / sqrt(1e-6) = 1e3), where LayerNorm-then-GEMM
+    (ViT_seq.c:103-121, then 134-147) has no such term.  Rows from "ordinary" down to exactly constant: the error against a float64
+    LayerNorm-then-GEMM stays within  rstd * 8 * 2^-24 * sum_k |x_k * Wf_k|  (the fp32 product chain's rounding, amplified) + 2e-5,
+    and for rows with the spread of real residual rows (rstd of order 1) within the 2e-5 bar every other fp32 op test uses."""
+    K, N = 768, 768
+    spreads = np.array([1.0, 1e-1, 1e-2, 1e-3, 1e-4, 0.0], np.float32)
+    M = 128 * len(spreads)
+    x = np.empty((M, K), np.float32)
+    for i, sp in enumerate(spreads):
+        x[128 * i:128 * (i + 1)] = u(40 + i, (128, 1), 2.0) + sp * u(50 + i, (128, K), 1.0)
+    gamma, beta = (1.0 + u(60, (K,), 0.5)).astype(np.float32), u(61, (K,), 0.5)
+    W, b = u(62, (N, K), 0.05), u(63, (N,), 0.1)
+    Wf, colsum, bias_f = B.ln_fold_weights_f32(W, b, gamma, beta)
+    rows = B.rowstats_f32(x)
+    got = B.gemm(x, Wf, bias_f, epilogue=B.EPI_BIAS, ln=(rows, colsum)).astype(np.float64)
+    x64 = x.astype(np.float64)
+    mean = x64.mean(1, keepdims=True)
+    var = (x64 * x64).mean(1, keepdims=True) - mean * mean
+    rstd = 1.0 / np.sqrt(np.maximum(var, 0.0) + 1e-6)
+    ref = ((x64 - mean) * rstd * gamma + beta) @ W.astype(np.float64).T + b
+    amp = rstd * (np.abs(x64) @ np.abs(Wf.astype(np.float64)).T)
+    err = np.abs(got - ref)
+    assert (err <= 8 * 2.0 ** -24 * amp + 2e-5).all(), float((err - 8 * 2.0 ** -24 * amp).max())
+    worst = [float(err[128 * i:128 * (i + 1)].max()) for i in range(len(spreads))]
+    print("fp32 fold, max |err| vs float64 LayerNorm-then-GEMM per row spread", dict(zip(spreads.tolist(), worst)))
+    assert worst[0] <= 2e-5 and worst[1] <= 2e-5        # rows like the residual stream's: the usual bar, no amplification visible
+    assert float(rstd[-1, 0]) == pytest.approx(1e3)     # constant rows: the largest amplification there is

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""EXPERIMENT (probe library): the four-wave bf16 GEMM (csrc/vit_gemm_bf16_w4.hip, 128 x 128 per wave) against the shipped
+"""EXPERIMENT (probe library): the four-wave bf16 GEMM (tools/probes/vit_gemm_bf16_w4.hip, 128 x 128 per wave) against the shipped
 ping-pong kernel -- first that it computes the same product, then launch times at the ViT shapes, interleaved.  GPU box only.
 
     VIT_HIP_LIBRARY=$PWD/vision-transformer-opencl_amd/libvit_mi355x_probe.so python3 tools/gemm_bf16_w4.py [batch] [b16|l16_384]

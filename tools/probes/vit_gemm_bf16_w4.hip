@@ -1,4 +1,4 @@
-// csrc/vit_gemm_bf16_w4.hip -- EXPERIMENT (probe build only, tools/gemm_bf16_w4.py): bf16 "NT" GEMM with FOUR waves per workgroup,
+// tools/probes/vit_gemm_bf16_w4.hip -- EXPERIMENT (probe build only, tools/gemm_bf16_w4.py): bf16 "NT" GEMM with FOUR waves per workgroup,
 // one per SIMD, each owning a 128 x 128 corner of the 256 x 256 tile.
 //
 // Why: the shipped kernel (vit_gemm_bf16_pp.hip, 8 waves x 128 x 64) reads 384 B of LDS per v_mfma_f32_16x16x32_bf16 -- 96 B/clk per

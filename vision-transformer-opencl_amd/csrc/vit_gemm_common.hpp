@@ -376,7 +376,7 @@ struct Bf16Params {
     float *partials;          // producer: [4 * tiles_n][M][2] partial (sum, sum of squares) per row and 64-column strip
 };
 int launch_gemm_bf16_pp(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);
-int launch_gemm_bf16_w4(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);  // probe build: vit_gemm_bf16_w4.hip
+int launch_gemm_bf16_w4(hipStream_t stream, const Bf16Params &p, int epilogue, int cus);  // probe build: tools/probes/vit_gemm_bf16_w4.hip
 // vit_gemm_latency.hip: 32x32 workgroup tiles on v_mfma_f32_16x16x4_f32 (bit-identical to the 32x32x2 kernels); K % 128 == 0
 int launch_gemm_f32_latency(hipStream_t stream, GemmParams &p, int epilogue);
 // vit_patch_embed_bf16.hip: patch embedding on the bf16 pipe as one implicit GEMM over the NCHW fp32 images
