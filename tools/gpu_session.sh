@@ -4,6 +4,7 @@
 # Steps run in the order given, joined by `set -e` (a failed or killed step ends the call: no GPU step runs behind a dead one).
 # Everything lands under gpurun_out/$VIT_ROUND (default r05).  Steps:
 #   suite               python -m pytest tests -m gpu -x -q              -> gpu_suite.log
+#   pytest:<tag>:<expr> python -m pytest tests -m gpu -q -k <expr>                -> pytest_<tag>.log
 #   bench               python bench.py (the driver's default line)       -> bench_default.json
 #   bench:<tag>:<args>  python bench.py <args> (',' separates arguments)  -> bench_<tag>.json
 #   sq:<tag>:<args>     SQ wait / issue counters of `bench.py <args>`     -> attn_issue_<tag>.csv (tools/sq_issue_summary.py)
@@ -24,6 +25,9 @@ for step in "$@"; do
     suite)
         timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > "$O/gpu_suite.log" 2>&1 || { tail -30 "$O/gpu_suite.log"; exit 1; }
         tail -1 "$O/gpu_suite.log" ;;
+    pytest)
+        timeout -k 10 900 python3 -m pytest tests -m gpu -x -q -s -k "$a" > "$O/pytest_$tag.log" 2>&1 || { tail -40 "$O/pytest_$tag.log"; exit 1; }
+        tail -5 "$O/pytest_$tag.log" ;;
     bench)
         if [ -z "$tag" ]; then tag=default; fi
         # shellcheck disable=SC2086
