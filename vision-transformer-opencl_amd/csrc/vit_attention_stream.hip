@@ -18,6 +18,16 @@
 // [issue DMA of step s+1] [S = K.Q^T, online softmax, O += V^T.P^T for my blocks] [one barrier].
 // MFMA layouts (v_mfma_f32_32x32x16_bf16, transposing LDS reads for V^T, P from accumulator to B operand in registers)
 // are those of attention_bf16_kernel.
+//
+// Round 5: the head switch no longer stops the workgroup.  (i) A wave normalises and stores a query block, re-initialises its
+// state and refills its Q slot for the NEXT head right after the block's last unit inside the head's last step -- beside the other
+// waves' units instead of as one burst behind a barrier.  (ii) Nothing waits for those refills with vmcnt(0) any more: every
+// vector-memory operation of the kernel is either inline-asm LDS-DMA or a bounds-checked buffer store with a scalar base, their
+// order per wave is fixed, so the waits are COUNTED (vmcnt retires in order): the barrier at the top of a head waits for the
+// head's first K/V chunk and the wave's first Q block only, and the first scores of the wave's second / third block wait for
+// that block's Q.  (iii) The 14 spilled VGPRs are gone (store addresses are one 32-bit lane offset + a scalar base, the Q / K
+// fragment addresses one lane register and an XOR per k-step): a spill reload is a vector load the compiler waits for with
+// vmcnt(0) -- which drained the ring's DMA inside the step and serialised the output stores behind each other.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -36,6 +46,7 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) short4v lds_short4v;
 typedef __attribute__((address_space(3))) void lds_void;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SHD = 64;                  // head_dim
 constexpr int ST_WAVES = 8, ST_THREADS = ST_WAVES * 64;
@@ -45,6 +56,9 @@ constexpr int SBUF = 2 * SKEYS * SHD;    // bf16 elements of one ring slot: K[12
 constexpr int MAXB = 3;                  // query blocks per wave: tokens <= 8 * 3 * 32 = 768
 constexpr int SUB = 2;                   // key tiles whose scores are in registers at a time
 constexpr float kScaleS = 0.125f * 1.4426950408889634f;
+#ifndef ST_MFMA_ROWSUM
+#define ST_MFMA_ROWSUM 1
+#endif
 #ifdef VIT_PROBES
 unsigned long long *g_stream_dbg = nullptr;
 #endif
@@ -146,6 +160,22 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    // "all but my n youngest vector-memory operations are done" for a wave-uniform run-time n (always even here: DMA pieces come in
+    // pairs, stores in fours).  A count the switch does not hold waits for everything.  vmcnt retires in issue order and counts the
+    // LDS-DMA pieces and the stores alike.
+    auto wait_vm = [&](int n) __attribute__((always_inline)) {
+        switch (n) {
+#define ST_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+            ST_VMW(2) ST_VMW(4) ST_VMW(6) ST_VMW(8) ST_VMW(10) ST_VMW(12) ST_VMW(14) ST_VMW(16) ST_VMW(18) ST_VMW(20)
+#undef ST_VMW
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    // LDS-DMA pieces this wave issues for chunk ch (dma_chunk below): two per group of 8 rows it owns
+    auto chunk_dmas = [&](int ch) __attribute__((always_inline)) {
+        const int rows = chunk_tiles(ch) * 32;
+        return 2 * ((8 * wave < rows ? 1 : 0) + (8 * (wave + ST_WAVES) < rows ? 1 : 0));
+    };
     auto dma_chunk = [&](int item, int ch, int slot) __attribute__((always_inline)) {
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));  // opaque: nothing below is loop-invariant to the compiler
@@ -183,25 +213,66 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     const int nblk = nkt;  // 32-row query blocks = 32-key tiles
     f32x16 o[MAXB][2];
     float m_run[MAXB], l_run[MAXB];
-    // Q blocks of this wave for `item` -> LDS (4 wave instructions of 8 rows per block); rows past the end are clamped
-    auto dma_q = [&](int item) __attribute__((always_inline)) {
+    constexpr bool MSUM = QS && ST_MFMA_ROWSUM;  // row sums from the matrix pipe (see softmax_pv)
+    const int h4 = 4 * h;
+    // Q block b of this wave for `item` -> LDS (4 wave instructions of 8 rows: ST_QDMA pieces); rows past the end are clamped
+    constexpr int ST_QDMA = 4, ST_STORES = 4;  // vector-memory operations per block: Q refill, output stores (finish_block)
+    auto dma_q_block = [&](int item, int b) __attribute__((always_inline)) {
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
         const int row_l = lane_l >> 3, pos = lane_l & 7;
         const int4v rq = make_rsrc4(item_base(item));
+        const int blk = wave + ST_WAVES * b;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            const int blk = wave + ST_WAVES * b;
-            if (blk < nblk) {  // wave-uniform
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int lrow = 8 * t + row_l;
-                    int srow = blk * 32 + lrow;
-                    srow = srow < tk ? srow : tk - 1;
-                    dma16(rq, Qs + blk * (32 * SHD) + t * 512, srow * ld * 2 + ((pos ^ ((lrow >> 1) & 7)) << 4), 0);
-                }
-            }
+        for (int t = 0; t < ST_QDMA; ++t) {
+            const int lrow = 8 * t + row_l;
+            int srow = blk * 32 + lrow;
+            srow = srow < tk ? srow : tk - 1;
+            dma16(rq, Qs + blk * (32 * SHD) + t * 512, srow * ld * 2 + ((pos ^ ((lrow >> 1) & 7)) << 4), 0);
         }
+    };
+    const int nb_wave = wave < nblk ? (nblk - 1 - wave) / ST_WAVES + 1 : 0;  // query blocks of this wave (wave-uniform)
+    auto init_block = [&](int b) __attribute__((always_inline)) {
+        m_run[b] = -INFINITY;
+        l_run[b] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[b][dt][v] = 0.0f;
+    };
+    // Normalise and store block b of `item`.  Buffer stores: base (the image's rows, scalar) + one 32-bit lane offset, the 16-byte
+    // piece's place as the instruction's scalar offset -- no 64-bit address per lane -- and rows past the last token are dropped by
+    // the descriptor's range check (num_records = the image's bytes) instead of a predicate.  Exactly ST_STORES instructions.
+    // A lane holds d = 8g + 4h + (0..3) of its row per column group g: 8-byte pieces, and a row-per-lane store of those is
+    // issue-bound (16 instructions of 64 scattered 8-byte pieces per block).  v_permlane32_swap trades group g of the upper
+    // half-wave for group g + 1 of the lower one: afterwards lanes 0-31 own d = 8g..8g+7 and lanes 32-63 d = 8g+8..8g+15 of their
+    // rows -- one 16-byte store per pair of groups, half the instructions (T21 of the CDNA4 guide).
+    auto finish_block = [&](int item, int b) __attribute__((always_inline)) {
+        const int img = item / heads, head = item % heads;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)img * tokens * D, 0, tokens * D * 2, 0x00020000);
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int voff = ((lane_l & 31) * D + 8 * (lane_l >> 5)) * 2;
+        const int soff = ((wave + ST_WAVES * b) * 32 * D + head * SHD) * 2;
+        float inv;
+        if constexpr (MSUM) inv = 1.0f / l_run[b];                              // both half-waves hold the whole row sum
+        else inv = 1.0f / (l_run[b] + __shfl_xor(l_run[b], 32));
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                bf16x4 w0, w1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w0[q] = (__bf16)(o[b][dt][4 * g + q] * inv);
+                    w1[q] = (__bf16)(o[b][dt][4 * (g + 1) + q] * inv);
+                }
+                uint2 a = __builtin_bit_cast(uint2, w0), c = __builtin_bit_cast(uint2, w1);
+                auto sx = __builtin_amdgcn_permlane32_swap(a.x, c.x, false, false);
+                auto sy = __builtin_amdgcn_permlane32_swap(a.y, c.y, false, false);
+                const u32x4 piece = {sx[0], sy[0], sx[1], sy[1]};  // lower half: [own g | upper's g]; upper: [lower's g+1 | own g+1]
+                __builtin_amdgcn_raw_buffer_store_b128(piece, ro, voff, soff + (dt * 32 + 8 * g) * 2, 0);
+            }
     };
 
     // One step = one chunk of one item, reading ring slot `slot` while the DMA of the following step fills the other one.
@@ -212,10 +283,15 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     // (1,900 cycles per unit measured).  So the units are software-pipelined -- the score MFMAs of the NEXT unit are issued
     // before the softmax of the current one, two score buffers alternate -- and the element-wise work is written on float
     // pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two values per instruction).
-    const int sw = (r >> 1) & 7, h4 = 4 * h;
+    //
+    // first: the item's first step -- the Q blocks of this wave may still be on their way (refilled during the previous item's last
+    //        step): block b's first scores wait for "all but q_younger[b] of my operations", counted.
+    // last:  the item's last step -- each block is normalised, stored, re-initialised and its Q slot refilled for next_item right
+    //        after its last unit.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    auto step = [&](int slot, int item, int ch, int next_item, int next_ch) __attribute__((always_inline)) {
+    auto step = [&](int slot, int item, int ch, int next_item, int next_ch, bool first, bool last) __attribute__((always_inline)) {
         asm volatile("" : "+s"(tk));
+        const int ncd = next_item >= 0 ? chunk_dmas(next_ch) : 0;  // operations the DMA below adds in front of everything later
         if (next_item >= 0) dma_chunk(next_item, next_ch, slot ^ 1);
         const bf16_t *Ks = lds + slot * SBUF, *Vs = Ks + SKEYS * SHD;
         const int key_base = chunk_first(ch) * 32;
@@ -228,10 +304,18 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
         // scores of sub-chunk k0 of block b -> buffer `buf`.  A sub-chunk is always computed whole: keys past `valid` (a
         // chunk of 3 tiles, the end of the sequence) hold older, finite data in LDS and are masked to -inf below.
         auto scores = [&](int buf, int b, int k0) __attribute__((always_inline)) {
-            const bf16_t *qrow = Qs + (wave + ST_WAVES * b) * (32 * SHD) + r * SHD;
+            // Row r of a 32-row block (Q or K alike) at r * 128 B, its 16-byte chunk c at position c ^ ((r >> 1) & 7); k-step ks
+            // wants chunk 2 ks + h, i.e. position ((h ^ sw) ^ 2 ks): ONE lane register and an XOR per k-step.  Recomputed from the
+            // lane id here: kept across the unit's softmax these addresses were what the allocator spilled.
+            int lane_l = lane;
+            asm volatile("" : "+v"(lane_l));
+            const int rr = lane_l & 31, hh = lane_l >> 5;
+            const int frag_l = rr * SHD + (((hh ^ (rr >> 1)) & 7) << 3);  // bf16 elements
+            if (first && k0 == 0 && b > 0) wait_vm((nb_wave - 1 - b) * (ST_QDMA + ST_STORES) + ncd);  // block b's Q has landed
+            const bf16_t *qblk = Qs + (wave + ST_WAVES * b) * (32 * SHD);
             bf16x8 qf[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qrow + (((2 * ks + h) ^ sw) & 7) * 8);
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qblk + (frag_l ^ (ks << 4)));
             float init = 0.0f;
             if constexpr (QS) {
                 const float mr = m_run[b];
@@ -248,7 +332,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             auto read_k = [&](int ks, int set) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < SUB; ++u)
-                    kf[set][u] = *reinterpret_cast<const bf16x8 *>(Ks + ((k0 + u) * 32 + r) * SHD + (((2 * ks + h) ^ sw) & 7) * 8);
+                    kf[set][u] = *reinterpret_cast<const bf16x8 *>(Ks + (k0 + u) * (32 * SHD) + (frag_l ^ (ks << 4)));
             };
             read_k(0, 0);
 #pragma unroll
@@ -306,16 +390,16 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                             st[buf][u][v + 1] = t[1];
                         }
                 }
-                float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                [[maybe_unused]] float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int u = 0; u < SUB; ++u)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
                         const float e = __builtin_amdgcn_exp2f(st[buf][u][v]);  // exp2(-inf) = 0: masked keys
                         st[buf][u][v] = e;
-                        s4[v & 3] += e;
+                        if constexpr (!MSUM) s4[v & 3] += e;
                     }
-                sum2 = f32x2{s4[0] + s4[1], s4[2] + s4[3]};
+                if constexpr (!MSUM) sum2 = f32x2{s4[0] + s4[1], s4[2] + s4[3]};
             } else {
                 m_new = (cmax - m_old) * kScaleS > kDefer ? cmax : m_old;  // first sub-chunk: m_old = -inf -> cmax (finite)
                 m_run[b] = m_new;
@@ -344,9 +428,14 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                         o[b][dt][v + 1] = w[1];
                     }
             }
-            l_run[b] += sum2[0] + sum2[1];
-            // P.V: the V^T fragments of 16-key group g+1 are read before the MFMAs of group g
+            if constexpr (!MSUM) l_run[b] += sum2[0] + sum2[1];
+            // P.V: the V^T fragments of 16-key group g+1 are read before the MFMAs of group g.
+            // MSUM: the row sums come out of the matrix pipe too -- one more MFMA per 16-key group with an all-ones A operand gives
+            // every register of `lsum` the sum of this lane's column of P over the group's 16 keys (both half-waves' keys: the
+            // product runs over k), i.e. the sum of the probabilities AS ROUNDED to bf16, the weights P.V really uses.  32 v_add_f32
+            // per unit leave the vector pipe, which is the busier one here (30 % matrix-busy against 55 % vector-busy per SIMD).
             bf16x8 vf[2][2];
+            [[maybe_unused]] f32x16 lsum;
             auto read_v = [&](int g, int set) __attribute__((always_inline)) {  // g = 2 u + s2
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) vf[set][dt] = v_frag_tr(Vs, (k0 + (g >> 1)) * 32 + 16 * (g & 1), dt, lane);
@@ -361,8 +450,20 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g & 1][dt], pf, o[b][dt], 0, 0, 0);
+                if constexpr (MSUM) {
+                    const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, g == 0 ? zero : lsum, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (MSUM) l_run[b] += lsum[0];
+        };
+        // a block's last unit of the head is behind it: out with it, and in with the next head's Q
+        auto retire_block = [&](int b) __attribute__((always_inline)) {
+            finish_block(item, b);
+            init_block(b);
+            if (next_item >= 0) dma_q_block(next_item, b);
         };
 
         // pipeline over this wave's blocks (wave, wave + 8, wave + 16: contiguous in b)
@@ -372,39 +473,10 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             if (wave + ST_WAVES * b >= nblk) continue;  // wave-uniform
             if (two) scores(1, b, SUB);                 // in the matrix pipe while the softmax below runs on the VALU
             softmax_pv(0, b, 0);
+            if (last && !two) retire_block(b);
             if (b + 1 < MAXB && wave + ST_WAVES * (b + 1) < nblk) scores(0, b + 1, 0);  // the next block's first scores
             if (two) softmax_pv(1, b, SUB);
-        }
-    };
-    auto finish_item = [&](int item) __attribute__((always_inline)) {  // normalise and store this wave's blocks
-        const int img = item / heads, head = item % heads;
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            const int row = (wave + ST_WAVES * b) * 32 + r;
-            const float inv = 1.0f / (l_run[b] + __shfl_xor(l_run[b], 32));  // all lanes take part in the exchange
-            if (wave + ST_WAVES * b < nblk) {  // wave-uniform: the half-wave exchange below needs every lane
-                // A lane holds d = 8g + 4h + (0..3) of its row per column group g: 8-byte pieces, and a row-per-lane store of
-                // those is issue-bound (16 instructions of 64 scattered 8-byte pieces per block).  v_permlane32_swap trades
-                // group g of the upper half-wave for group g + 1 of the lower one: afterwards lanes 0-31 own d = 8g..8g+7 and
-                // lanes 32-63 d = 8g+8..8g+15 of their rows -- one 16-byte store per pair of groups, half the instructions.
-                bf16_t *dst = out + ((size_t)img * tokens + row) * D + head * SHD + 8 * h;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; g += 2) {
-                        bf16x4 w0, w1;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            w0[q] = (__bf16)(o[b][dt][4 * g + q] * inv);
-                            w1[q] = (__bf16)(o[b][dt][4 * (g + 1) + q] * inv);
-                        }
-                        uint2 a = __builtin_bit_cast(uint2, w0), c = __builtin_bit_cast(uint2, w1);
-                        auto sx = __builtin_amdgcn_permlane32_swap(a.x, c.x, false, false);
-                        auto sy = __builtin_amdgcn_permlane32_swap(a.y, c.y, false, false);
-                        const uint4 piece = {sx[0], sy[0], sx[1], sy[1]};  // lower half: [own g | upper's g]; upper: [lower's g+1 | own g+1]
-                        if (row < tokens) *reinterpret_cast<uint4 *>(dst + dt * 32 + 8 * g) = piece;
-                    }
-            }
+            if (last && two) retire_block(b);
         }
     };
 
@@ -416,42 +488,37 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     __syncthreads();
     dma_chunk(item, 0, 0);
     int slot = 0;
-
-    dma_q(item);
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        init_block(b);
+        if (wave + ST_WAVES * b < nblk) dma_q_block(item, b);
+    }
+    bool first_item = true;
     for (;;) {  // items
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            m_run[b] = -INFINITY;
-            l_run[b] = 0.0f;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) o[b][dt][v] = 0.0f;
-        }
-        // this head's Q blocks and the chunk that is about to be read (all LDS-DMA) have landed after this barrier
+        // The head's first K/V chunk (every wave's pieces: hence the barrier) and THIS wave's first Q block have landed; its other
+        // Q blocks may still be in flight.  Operations of this wave younger than block 0's refill: the (stores + refill) of its
+        // other blocks.  The very first head has no stores in the queue: wait for everything.
         ST_STAMP();
-        ring_barrier();
+        wait_vm(first_item ? 0 : (nb_wave - 1) * (ST_QDMA + ST_STORES));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         ST_STAMP();
         const int next_item = item + stride;
         for (int ch = 0; ch < nch; ++ch) {
             // the step after this one: the next chunk of this head, or the first chunk of the next head
             const int ni = ch + 1 < nch ? item : (next_item < n_items ? next_item : -1);
             const int nc = ch + 1 < nch ? ch + 1 : 0;
-            step(slot, item, ch, ni, nc);
+            step(slot, item, ch, ni, nc, ch == 0 && !first_item, ch == nch - 1);
             ST_STAMP();
-            if (ch == nch - 1) {
-                // (Tried: normalising and storing a block, and refilling its Q slot, right after its last unit inside the last
-                // step, so that the stores run beside the other waves' work instead of as one burst: no gain, 2.35 vs 2.35 ms.)
-                finish_item(item);
-                if (next_item < n_items) dma_q(next_item);  // this wave is done with its Q blocks: refill them for the next head
-            }
             slot ^= 1;
             if (ch + 1 < nch) ring_barrier();  // the next chunk has landed, everybody is done with this one
             ST_STAMP();
-            // (after the last chunk the barrier is the one at the top of the next item, behind its Q loads)
+            // (after the last chunk the barrier is the one at the top of the next item, behind the counted wait)
         }
         if (next_item >= n_items) break;
         item = next_item;
+        first_item = false;
 #ifdef VIT_PROBES
         ++it_no;
 #endif
@@ -492,7 +559,8 @@ int attention_bf16_stream(hipStream_t s, const unsigned short *qkv, unsigned sho
     if (cus <= 0) return static_cast<int>(hipErrorInvalidDevice);
     const int nblk = (tokens + 31) / 32;
     const size_t lds_bytes = (size_t)(2 * SBUF + nblk * 32 * SHD) * sizeof(bf16_t);  // ring + the head's Q blocks
-    if (tokens > ST_WAVES * MAXB * 32 || lds_bytes > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+    // at least two K/V chunks per head: the counted waits of the kernel assume that a head's first and last step are different steps
+    if (tokens > ST_WAVES * MAXB * 32 || nblk <= SKT || lds_bytes > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     const int items = n_images * heads;
     const int grid = items < cus ? items : cus;
     return q_scaled ? launch_stream<true>(s, qkv, out, tokens, heads, items, grid, lds_bytes, dev)
