@@ -29,7 +29,7 @@ def listings(tmp_path_factory):
 
 def test_every_inline_asm_site_keeps_its_hazard_and_wait_invariants(listings):
     """tools/check_inline_asm.py over every kernel file with inline assembly: (i) no write of a wide asm store's data registers
-    within two wait states, (ii) no use of an asm load's destination before the counted wait that retires it (rounds 1-4 checked this for one file and one instruction only), (iii) every asm LDS-DMA sets M0 in its own block."""
+    within two wait states, (ii) no use of an asm load's destination before the counted wait that retires it (rounds 1-4 checked this for one file and one instruction only), (iii) every asm LDS-DMA sets M0 in its own block, (iv) no compiler-made 16-byte buffer store with a register in soffset in front of a write of its data."""
     d, r = listings
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
@@ -80,6 +80,17 @@ def test_the_lint_fails_on_deliberately_broken_sites(listings):
     mut = lines[:blk[1] + 1] + [f"\tv_add_f32_e32 v0, v{reg}, v0"] + lines[blk[1] + 1:]
     found = lint.check_text("\n".join(mut))[0]
     assert len(found) == 1 and "still in flight" in found[0], found
+
+    # (iv) a compiler-made 16-byte buffer store with a REGISTER in soffset (the form hipcc does not pad: it cost the streamed attention
+    # its rows 12-15 / 28-31 in round 5), data register written in the next slot
+    alines = open(os.path.join(d, "vit_attention_stream.s")).read().split("\n")
+    k = next(i for i, l in enumerate(alines) if re.search(r"buffer_store_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\], 0 offen", l))
+    reg = re.search(r"buffer_store_dwordx4 v\[(\d+):", alines[k]).group(1)
+    mut = alines[:k] + [re.sub(r", 0 offen", ", s44 offen", alines[k], count=1), f"\tv_mul_f32_e32 v{reg}, v1, v1"] + alines[k + 1:]
+    found = lint.check_text("\n".join(mut))[0]
+    assert len(found) == 1 and "compiler-made store" in found[0], found
+    same_with_immediate = alines[:k + 1] + [f"\tv_mul_f32_e32 v{reg}, v1, v1"] + alines[k + 1:]   # soffset 0: hipcc's own padding applies
+    assert lint.check_text("\n".join(same_with_immediate))[0] == []
 
     # (iii) LDS-DMA of the fp32 persistent GEMM (the rows' pairs of the LayerNorm fold): drop the s_nop behind the M0 write
     lines = open(os.path.join(d, "vit_gemm_persistent.s")).read().split("\n")

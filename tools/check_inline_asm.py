@@ -2,8 +2,8 @@
 """ISA-level lint of every `asm volatile` site in csrc/*.hip (CPU only: hipcc -S for gfx950, no GPU).
 
 hipcc treats an asm statement as one opaque instruction: it neither counts the memory operations inside nor pads
-their hazards (CDNA4 guide 5.7).  The kernels here rely on three hand-kept invariants; this script re-derives each
-from the generated assembly, so the next edit (or the next register allocation) cannot silently break them:
+their hazards (CDNA4 guide 5.7).  The kernels here rely on three hand-kept invariants -- and on one thing hipcc itself gets wrong, (iv) --; this script
+re-derives each from the generated assembly, so the next edit (or the next register allocation) cannot silently break them:
 
   (i)   STORE DATA HAZARD.  A vector-memory store of more than 8 bytes keeps reading its data registers for two wait
         states after issue (gfx940+: LLVM's hazard recognizer pads 2 for its own stores, nothing behind `;;#ASMEND`).
@@ -17,6 +17,11 @@ from the generated assembly, so the next edit (or the next register allocation) 
   (iii) LDS-DMA THROUGH M0.  An asm `buffer_load ... lds` / `global_load_lds_*` takes its LDS base from M0, which the
         compiler does not preserve: the same asm block must write M0 first, with at least one wait state (`s_nop 0`)
         between the SALU write and the load.
+
+  (iv)  WIDE BUFFER STORE WITH A SCALAR OFFSET (compiler-made code: found in round 5).  LLVM's hazard recognizer pads the two
+        wait states of (i) for its own stores EXCEPT for buffer stores whose soffset is a register; on gfx950 that form has the
+        hazard too (a v_mul in the next slot overwrote the data of the lanes read last).  Reported like (i), for every
+        `buffer_store_dwordx3/x4 ..., sN offen` outside asm.
 
     python tools/check_inline_asm.py            # every csrc/*.hip with `asm volatile`; exit 1 on any finding
     python tools/check_inline_asm.py --asm f.s  # lint an assembly file as it is (what the self-test mutates)
@@ -123,16 +128,20 @@ def check_kernel(name: str, body: list[Inst]) -> list[str]:
 
     # ---- (i) wide asm stores: two wait states before a write of the data registers
     for i, ins in enumerate(body):
-        if not (ins.in_asm and VM_STORE.match(ins.op) and WIDE.search(ins.op)):
+        if not (VM_STORE.match(ins.op) and WIDE.search(ins.op)):
             continue
+        if not ins.in_asm:  # (iv): the compiler pads its own wide stores, except buffer stores with a register in soffset
+            if not (ins.op.startswith("buffer_") and len(ins.operands) >= 4 and re.match(r"^s\d+\b", ins.operands[3])):
+                continue
         # data operand: global_store vaddr, vdata, saddr|off ; buffer_store vdata, vaddr, srsrc, ...
         data = ins.operands[0] if ins.op.startswith("buffer_") else ins.operands[1]
         dregs, states, j = regs_of(data), 0, i + 1
         while states < 2 and j < len(body):
             nxt = body[j]
             if nxt.op != "s_nop" and (nxt.written_vregs() & dregs):
-                found.append(f"{short}: line {nxt.line}: `{nxt.text}` writes data registers of the asm store at line {ins.line} "
-                             f"(`{ins.text}`) after {states} wait state(s); a store of more than 8 bytes needs 2 (end the asm string in `s_nop 1`)")
+                how = "end the asm string in `s_nop 1`" if ins.in_asm else "keep the scalar offset out of soffset: hipcc pads the other forms itself"
+                found.append(f"{short}: line {nxt.line}: `{nxt.text}` writes data registers of the {'asm' if ins.in_asm else 'compiler-made'} store at "
+                             f"line {ins.line} (`{ins.text}`) after {states} wait state(s); a store of more than 8 bytes needs 2 ({how})")
                 break
             states += nxt.wait_states()
             j += 1

@@ -5,6 +5,7 @@
 # Everything lands under gpurun_out/$VIT_ROUND (default r05).  Steps:
 #   suite               python -m pytest tests -m gpu -x -q              -> gpu_suite.log
 #   pytest:<tag>:<expr> python -m pytest tests -m gpu -q -k <expr>                -> pytest_<tag>.log
+#   abtest:<tag>:<lib>:<expr>  the same tests against another build of the library, all failures listed -> pytest_<tag>.log
 #   bench               python bench.py (the driver's default line)       -> bench_default.json
 #   bench:<tag>:<args>  python bench.py <args> (',' separates arguments)  -> bench_<tag>.json
 #   sq:<tag>:<args>     SQ wait / issue counters of `bench.py <args>`     -> attn_issue_<tag>.csv (tools/sq_issue_summary.py)
@@ -28,6 +29,9 @@ for step in "$@"; do
     pytest)
         timeout -k 10 900 python3 -m pytest tests -m gpu -x -q -s -k "$a" > "$O/pytest_$tag.log" 2>&1 || { tail -40 "$O/pytest_$tag.log"; exit 1; }
         tail -5 "$O/pytest_$tag.log" ;;
+    abtest)
+        VIT_HIP_LIBRARY=$PWD/$a timeout -k 10 900 python3 -m pytest tests -m gpu -q -k "$b" > "$O/pytest_$tag.log" 2>&1 || true
+        grep -E "^(FAILED|ERROR)|passed|failed" "$O/pytest_$tag.log" | tail -30 ;;
     bench)
         if [ -z "$tag" ]; then tag=default; fi
         # shellcheck disable=SC2086

@@ -241,8 +241,8 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             for (int v = 0; v < 16; ++v) o[b][dt][v] = 0.0f;
     };
     // Normalise and store block b of `item`.  Buffer stores: base (the image's rows, scalar) + one 32-bit lane offset, the 16-byte
-    // piece's place as the instruction's scalar offset -- no 64-bit address per lane -- and rows past the last token are dropped by
-    // the descriptor's range check (num_records = the image's bytes) instead of a predicate.  Exactly ST_STORES instructions.
+    // piece's place as the instruction's immediate offset -- no 64-bit address per lane -- and rows past the last token are dropped
+    // by the descriptor's range check (num_records = the image's bytes) instead of a predicate.  Exactly ST_STORES instructions.
     // A lane holds d = 8g + 4h + (0..3) of its row per column group g: 8-byte pieces, and a row-per-lane store of those is
     // issue-bound (16 instructions of 64 scattered 8-byte pieces per block).  v_permlane32_swap trades group g of the upper
     // half-wave for group g + 1 of the lower one: afterwards lanes 0-31 own d = 8g..8g+7 and lanes 32-63 d = 8g+8..8g+15 of their
@@ -252,8 +252,12 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)img * tokens * D, 0, tokens * D * 2, 0x00020000);
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
-        const int voff = ((lane_l & 31) * D + 8 * (lane_l >> 5)) * 2;
-        const int soff = ((wave + ST_WAVES * b) * 32 * D + head * SHD) * 2;
+        // The block's and head's offset goes into the LANE offset, not into the instruction's scalar offset: for a 16-byte buffer
+        // store whose soffset is a register hipcc (ROCm 7.2) pads no wait state in front of a write of the data registers -- LLVM's
+        // hazard recognizer exempts exactly that form -- and on gfx950 the next v_mul then overwrote the data of the lanes the store
+        // reads last ((lane >> 2) & 3 == 3: query rows 12-15 and 28-31 of a block came out wrong, from run to run, on the
+        // second-dispatched waves).  With soffset = 0 the two wait states are there.  tools/check_inline_asm.py rule (iv).
+        const int voff = ((lane_l & 31) * D + 8 * (lane_l >> 5)) * 2 + ((wave + ST_WAVES * b) * 32 * D + head * SHD) * 2;
         float inv;
         if constexpr (MSUM) inv = 1.0f / l_run[b];                              // both half-waves hold the whole row sum
         else inv = 1.0f / (l_run[b] + __shfl_xor(l_run[b], 32));
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                 auto sx = __builtin_amdgcn_permlane32_swap(a.x, c.x, false, false);
                 auto sy = __builtin_amdgcn_permlane32_swap(a.y, c.y, false, false);
                 const u32x4 piece = {sx[0], sy[0], sx[1], sy[1]};  // lower half: [own g | upper's g]; upper: [lower's g+1 | own g+1]
-                __builtin_amdgcn_raw_buffer_store_b128(piece, ro, voff, soff + (dt * 32 + 8 * g) * 2, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(piece, ro, voff + (dt * 32 + 8 * g) * 2, 0, 0);  // + immediate
             }
     };
 
@@ -434,8 +438,15 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             // every register of `lsum` the sum of this lane's column of P over the group's 16 keys (both half-waves' keys: the
             // product runs over k), i.e. the sum of the probabilities AS ROUNDED to bf16, the weights P.V really uses.  32 v_add_f32
             // per unit leave the vector pipe, which is the busier one here (30 % matrix-busy against 55 % vector-busy per SIMD).
+            // Only element 0 of the sums' accumulator is ever read and its 16 elements are independent sums, so 15 of the registers stay
+            // uninitialised (the empty asm "defines" them without an instruction) and element 0 starts as the running sum itself:
+            // no zeroing, no add afterwards.
             bf16x8 vf[2][2];
             [[maybe_unused]] f32x16 lsum;
+            if constexpr (MSUM) {
+                asm volatile("" : "=v"(lsum));
+                lsum[0] = l_run[b];
+            }
             auto read_v = [&](int g, int set) __attribute__((always_inline)) {  // g = 2 u + s2
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) vf[set][dt] = v_frag_tr(Vs, (k0 + (g >> 1)) * 32 + 16 * (g & 1), dt, lane);
@@ -452,12 +463,11 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                 for (int dt = 0; dt < 2; ++dt) o[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g & 1][dt], pf, o[b][dt], 0, 0, 0);
                 if constexpr (MSUM) {
                     const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, g == 0 ? zero : lsum, 0, 0, 0);
+                    lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lsum, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (MSUM) l_run[b] += lsum[0];
+            if constexpr (MSUM) l_run[b] = lsum[0];
         };
         // a block's last unit of the head is behind it: out with it, and in with the next head's Q
         auto retire_block = [&](int b) __attribute__((always_inline)) {
