@@ -102,8 +102,8 @@ def test_fold_arguments_are_validated():
 def test_fp32_fold_on_near_constant_rows_stays_inside_its_stated_bound():
     """include/vit_hip_kernels.h (ln_rows): the fp32 fold computes rstd * (x . Wf^T - mean * colsum) + b', so on a row of small
     variance the cancellation error of the bracket is scaled by rstd (at most 1 / sqrt(1e-6) = 1e3), where LayerNorm-then-GEMM
-    (ViT_seq.c:103-121, then 134-147) has no such term.  Rows from "ordinary" down to exactly constant, against the UNFOLDED path on
-    the same statistics (the LayerNorm kernel, then the plain GEMM: the reference's operation order): the difference stays within
+    (ViT_seq.c:103-121, then 134-147) has no such term.  Rows from "ordinary" down to exactly constant, against a float64
+    LayerNorm-then-GEMM on the same (rstd, mean) pairs (the reference's operation order): the difference stays within
     rstd * 8 * 2^-24 * sum_k |x_k * Wf_k|  (the fp32 product chain's rounding, amplified) + 2e-5, and within the 2e-5 bar of every
     other fp32 op test for rows with the spread of real residual rows (rstd of order 1).
     The constant rows are 2.0, -0.5 and 0.0 everywhere -- values whose mean and mean of squares are exact in fp32.  (Rows that are
@@ -123,12 +123,19 @@ def test_fp32_fold_on_near_constant_rows_stays_inside_its_stated_bound():
     assert np.isfinite(rows).all()
     assert np.allclose(rows[128 * len(spreads):, 0], 1e3, rtol=1e-6)      # constant rows: var = 0 exactly, rstd = 1 / sqrt(1e-6)
     got = B.gemm(x, Wf, bias_f, epilogue=B.EPI_BIAS, ln=(rows, colsum)).astype(np.float64)
-    unfolded = B.gemm(B.layernorm(x, gamma, beta), W, b, epilogue=B.EPI_BIAS).astype(np.float64)
-    assert np.isfinite(got).all() and np.isfinite(unfolded).all()
-    amp = rows[:, :1].astype(np.float64) * (np.abs(x.astype(np.float64)) @ np.abs(Wf.astype(np.float64)).T)
-    err = np.abs(got - unfolded)
+    assert np.isfinite(got).all()
+    # LayerNorm-then-GEMM in float64 with the SAME (rstd, mean) pairs: what is measured is the fold's arithmetic, not the statistics
+    # (two fp32 evaluations of var = E[x^2] - mean^2 in different summation orders -- the LayerNorm kernel's and this one -- already
+    # differ by several per cent in rstd on the spread-0.01 rows: that ill-conditioning is the reference's formula, fold or no fold)
+    x64, r64 = x.astype(np.float64), rows.astype(np.float64)
+    ref = ((x64 - r64[:, 1:]) * r64[:, :1] * gamma + beta) @ W.astype(np.float64).T + b
+    amp = r64[:, :1] * (np.abs(x64) @ np.abs(Wf.astype(np.float64)).T)
+    err = np.abs(got - ref)
     assert (err <= 8 * 2.0 ** -24 * amp + 2e-5).all(), float((err - 8 * 2.0 ** -24 * amp).max())
     worst = {("spread %g" % sp): float(err[128 * i:128 * (i + 1)].max()) for i, sp in enumerate(spreads)}
     worst["constant rows (rstd 1e3)"] = float(err[128 * len(spreads):].max())
-    print("fp32 fold vs LayerNorm-then-GEMM, max |difference| per kind of row:", worst)
+    print("fp32 fold vs float64 LayerNorm-then-GEMM on the same statistics, max |difference| per kind of row:", worst)
     assert worst["spread 1"] <= 2e-5 and worst["spread 0.1"] <= 2e-5    # rows like the residual stream's: no amplification visible
+    # and the unfolded path (LayerNorm kernel, then the plain GEMM) agrees where the statistics are well-conditioned
+    unfolded = B.gemm(B.layernorm(x[:256], gamma, beta), W, b, epilogue=B.EPI_BIAS).astype(np.float64)
+    assert float(np.abs(got[:256] - unfolded).max()) <= 2e-5
