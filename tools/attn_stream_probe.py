@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time and stamp the streamed bf16 attention kernel at ViT-L/16-384 (probe build for the stamps). GPU box only.
+"""Time and stamp the streamed bf16 attention kernel at ViT-L/16-384 (probe build for the stamps); `2048 197 12` times the resident
+kernel at ViT-B/16's shape.  GPU box only.
 VIT_TOOL_DATA=zeros: an all-zero qkv (the same instructions at a lower power draw: is the kernel clock-limited?)."""
 import importlib, json, os, sys, ctypes as C
 import numpy as np
@@ -7,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 B = importlib.import_module("vision-transformer-opencl_amd.binding")
 from tools.gemm_probe import timed
-n, T, heads = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 577, 16
+n, T, heads = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 577, int(sys.argv[3]) if len(sys.argv) > 3 else 16
 D = heads * 64
 rng = np.random.default_rng(0)
 vals = rng.uniform(-1.5, 1.5, (n * T, 3 * D)).astype(np.float32)

@@ -555,19 +555,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mxs = -mx * kScale;
-            float sum = 0.0f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
-                    st[kt][v] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
+                for (int v = 0; v < 16; ++v) st[kt][v] = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
 
-            // ---- O^T = V^T . P^T --------------------------------------------------------------------------
+            // ---- O^T = V^T . P^T, and the row sums from the same pipe ---------------------------------------
+            // One more MFMA per 16-key group with an all-ones A operand: every element of `lsum` becomes the sum of this lane's
+            // column of P over the group's keys (both half-waves' keys: the product runs over k) -- the sum of the probabilities AS
+            // ROUNDED to bf16, the weights P.V really uses.  16 x NKT v_add_f32 per lane and the half-wave exchange leave the vector
+            // pipe, the busier one in this kernel.  Only element 0 is read and the elements are independent sums: the other 15
+            // registers stay uninitialised (the empty asm "defines" them without an instruction).
+            f32x16 lsum;
+            asm volatile("" : "=v"(lsum));
+            lsum[0] = 0.0f;
+            const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
             f32x16 o[2];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -584,9 +586,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt)
                             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_fragment_tr(Vs, kt * 32 + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
+                        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lsum, 0, 0, 0);
                     }
                 }
             }
+            const float inv = 1.0f / lsum[0];
 
             {
                 // 16-byte stores: v_permlane32_swap trades column group g of the upper half-wave for group g + 1 of the lower one,
