@@ -67,6 +67,9 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, f32x4 v) {
 constexpr int HD = 64;          // head_dim (ViT-B/16 and ViT-L/16)
 constexpr int K_LD = HD + 4;    // padded K row (floats): conflict-free ds_read_b128 over 32 rows
 constexpr int ATT_THREADS = 512;
+#ifndef ATT_STAGGER
+#define ATT_STAGGER 14
+#endif
 constexpr int ATT_WAVES = ATT_THREADS / 64;
 
 #ifdef VIT_PROBES
@@ -524,6 +527,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
         if (next < items) fetch(next);  // in flight during everything below
 
         if (computes) {
+            // The two waves of a SIMD (w and w + 4) leave the barrier together and would run their matrix phases (S, then P.V) and
+            // their softmax in step -- twice the matrix time, no overlap of the two pipes.  Waves 4-7 start ATT_STAGGER x 64 cycles
+            // late: their S falls into their partners' softmax, their softmax into the partners' P.V (vit_attention_stream.hip).
+            if (ATT_STAGGER > 0 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(ATT_STAGGER);
             // ---- S^T = K . Q^T ------------------------------------------------------------------------
             f32x16 st[NKT];
             const int sw = (r >> 1) & 7;

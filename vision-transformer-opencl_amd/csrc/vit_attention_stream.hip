@@ -59,6 +59,19 @@ constexpr float kScaleS = 0.125f * 1.4426950408889634f;
 #ifndef ST_MFMA_ROWSUM
 #define ST_MFMA_ROWSUM 1
 #endif
+// The two waves of a SIMD (w and w + 4) run the same program and leave every barrier together: left alone they issue their score /
+// P.V MFMAs at the same time (each burst then takes twice as long: one matrix pipe) and their softmax at the same time -- the unit
+// is [512 MFMA cycles][576 VALU][...] per wave and NOTHING overlaps (stamps: 2,150 cycles per unit with the partner active, 1,216
+// alone).  ST_STAGGER: waves 4-7 start every step ST_STAGGER x 64 cycles late (they issue the step's ring DMA first, then sleep),
+// so that their matrix bursts fall into their partners' softmax and vice versa (CDNA4 guide, two waves per SIMD, item 9).  They
+// own one query block fewer than waves 0-2, so the delay is off the step's critical path.  ST_DMA_LATE: waves 0-3 issue their share
+// of the ring DMA after their first unit instead of at the step's start.
+#ifndef ST_STAGGER
+#define ST_STAGGER 8
+#endif
+#ifndef ST_DMA_LATE
+#define ST_DMA_LATE 1
+#endif
 #ifdef VIT_PROBES
 unsigned long long *g_stream_dbg = nullptr;
 #endif
@@ -296,7 +309,9 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     auto step = [&](int slot, int item, int ch, int next_item, int next_ch, bool first, bool last) __attribute__((always_inline)) {
         asm volatile("" : "+s"(tk));
         const int ncd = next_item >= 0 ? chunk_dmas(next_ch) : 0;  // operations the DMA below adds in front of everything later
-        if (next_item >= 0) dma_chunk(next_item, next_ch, slot ^ 1);
+        const bool dma_late = ST_DMA_LATE && wave < 4;  // wave-uniform
+        if (next_item >= 0 && !dma_late) dma_chunk(next_item, next_ch, slot ^ 1);
+        if (ST_STAGGER > 0 && wave >= 4) __builtin_amdgcn_s_sleep(ST_STAGGER);
         const bf16_t *Ks = lds + slot * SBUF, *Vs = Ks + SKEYS * SHD;
         const int key_base = chunk_first(ch) * 32;
         int valid = chunk_tiles(ch) * 32;                      // keys of this chunk ...
@@ -483,6 +498,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             if (wave + ST_WAVES * b >= nblk) continue;  // wave-uniform
             if (two) scores(1, b, SUB);                 // in the matrix pipe while the softmax below runs on the VALU
             softmax_pv(0, b, 0);
+            if (b == 0 && dma_late && next_item >= 0) dma_chunk(next_item, next_ch, slot ^ 1);  // (in front of everything the waits count)
             if (last && !two) retire_block(b);
             if (b + 1 < MAXB && wave + ST_WAVES * (b + 1) < nblk) scores(0, b + 1, 0);  // the next block's first scores
             if (two) softmax_pv(1, b, SUB);
