@@ -68,7 +68,7 @@ constexpr int HD = 64;          // head_dim (ViT-B/16 and ViT-L/16)
 constexpr int K_LD = HD + 4;    // padded K row (floats): conflict-free ds_read_b128 over 32 rows
 constexpr int ATT_THREADS = 512;
 #ifndef ATT_STAGGER
-#define ATT_STAGGER 14
+#define ATT_STAGGER 0   // measured at ViT-B/16 batch 2048: 0 / 8 / 14 / 20 x 64 cycles = 0.582 / 0.586 / 0.582 / 0.591 ms: nothing, off
 #endif
 constexpr int ATT_WAVES = ATT_THREADS / 64;
 

@@ -56,8 +56,11 @@ constexpr int SBUF = 2 * SKEYS * SHD;    // bf16 elements of one ring slot: K[12
 constexpr int MAXB = 3;                  // query blocks per wave: tokens <= 8 * 3 * 32 = 768
 constexpr int SUB = 2;                   // key tiles whose scores are in registers at a time
 constexpr float kScaleS = 0.125f * 1.4426950408889634f;
+// Row sums from the matrix pipe (softmax_pv): built, exact to the bf16 rounding of P, and measured SLOWER here (2.37 against 2.22 ms per
+// launch at ViT-L/16-384, batch 1024: the four extra MFMAs per unit cost more than the 32 v_add_f32 they replace -- the resident
+// kernel of vit_attention.hip, whose units are longer, gains 1 % from the same change and keeps it).  Off.
 #ifndef ST_MFMA_ROWSUM
-#define ST_MFMA_ROWSUM 1
+#define ST_MFMA_ROWSUM 0
 #endif
 // The two waves of a SIMD (w and w + 4) run the same program and leave every barrier together: left alone they issue their score /
 // P.V MFMAs at the same time (each burst then takes twice as long: one matrix pipe) and their softmax at the same time -- the unit
@@ -66,11 +69,17 @@ constexpr float kScaleS = 0.125f * 1.4426950408889634f;
 // so that their matrix bursts fall into their partners' softmax and vice versa (CDNA4 guide, two waves per SIMD, item 9).  They
 // own one query block fewer than waves 0-2, so the delay is off the step's critical path.  ST_DMA_LATE: waves 0-3 issue their share
 // of the ring DMA after their first unit instead of at the step's start.
+// Measured (interleaved, one device, ms per launch at ViT-L/16-384 batch 1024; round 4's kernel 2.317): no stagger 2.245, 4 x 64
+// cycles 2.189, 8 x 64 2.220; a static s_setprio(1) for waves 4-7 on top: 2.33 (worse).  The model above promised far more than the
+// 2.5 % the stagger gives: the partners fall back into step inside the step (profiles/r05/experiments).
 #ifndef ST_STAGGER
-#define ST_STAGGER 8
+#define ST_STAGGER 4
 #endif
 #ifndef ST_DMA_LATE
 #define ST_DMA_LATE 1
+#endif
+#ifndef ST_PRIO
+#define ST_PRIO 0
 #endif
 #ifdef VIT_PROBES
 unsigned long long *g_stream_dbg = nullptr;
@@ -509,6 +518,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     int item = blockIdx.x;
     if (item >= n_items) return;  // workgroup-uniform
     const int stride = gridDim.x;
+    if (ST_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses the issue arbitration otherwise (T5, static form)
     // the ring starts zeroed: stale rows that a partial sub-chunk multiplies by 0 must be finite from the first step on
     for (int i = tid; i < 2 * SBUF / 8; i += ST_THREADS) reinterpret_cast<uint4 *>(lds)[i] = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
