@@ -58,6 +58,10 @@ typedef struct {
                       * meet the 1e-4 bar against ViT_seq.c, the folded one is not the same bits as the unfolded one. */
     int gemm_handover_test; /* testing: vithip_gemm_args.handover_test for every fp32 GEMM (1 = helper pieces arrive too late and
                              * every owner computes its whole tile; results must not change) */
+    int host_first_piece;   /* vit_engine_forward_host(): images in the FIRST piece of a call (nothing overlaps its gather and upload,
+                             * so it is a small one; the rest follows behind its compute in pieces of max_batch).  0 = auto (the
+                             * measured choice, host/vit_engine.c), otherwise clamped to [1, max_batch].  Rows are bit-identical
+                             * whatever the cut. */
 } vit_engine_options;
 
 enum { VIT_DTYPE_F32 = 0, VIT_DTYPE_BF16 = 1 };

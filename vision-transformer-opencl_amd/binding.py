@@ -49,7 +49,7 @@ class CImageData(C.Structure):  # Network.h:7-13
 class COptions(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("profile", C.c_int), ("lanes", C.c_int),
                 ("dtype", C.c_int), ("prune_last_layer", C.c_int), ("use_graph", C.c_int), ("gemm_tile", C.c_int), ("ln_fold", C.c_int),
-                ("gemm_handover_test", C.c_int)]
+                ("gemm_handover_test", C.c_int), ("host_first_piece", C.c_int)]
 
 
 class CStageTimes(C.Structure):
@@ -583,12 +583,12 @@ class Engine:
 
     def __init__(self, cfg: ModelConfig, max_batch: int = 256, device: int = 0, profile: bool = False,
                  lanes: int = 1, dtype: str = "f32", prune_last_layer: bool = False, use_graph: bool = False,
-                 gemm_tile: int = 0, ln_fold: int = 0, gemm_handover_test: int = 0):
+                 gemm_tile: int = 0, ln_fold: int = 0, gemm_handover_test: int = 0, host_first_piece: int = 0):
         self.cfg = cfg
         self._h = C.c_void_p()
         cc = CConfig.of(cfg)
         opt = COptions(device, max_batch, 1 if profile else 0, lanes, {"f32": 0, "bf16": 1}[dtype],
-                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold, gemm_handover_test)
+                       1 if prune_last_layer else 0, 1 if use_graph else 0, gemm_tile, ln_fold, gemm_handover_test, host_first_piece)
         rc = lib().vit_engine_create(C.byref(self._h), C.byref(cc), C.byref(opt))
         if rc != 0:
             msg = lib().vit_engine_last_error(self._h).decode() if self._h else "allocation failed"

@@ -19,6 +19,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <omp.h>
 #include <string.h>
 
 #include "vit_hip_kernels.h"
@@ -135,6 +136,7 @@ void vit_engine_default_options(vit_engine_options *opt) {
     opt->gemm_tile = 0;
     opt->ln_fold = 0;
     opt->gemm_handover_test = 0;
+    opt->host_first_piece = 0;
 }
 
 static int fail(vit_engine *e, int code, const char *fmt, ...) {
@@ -1078,15 +1080,21 @@ int vit_engine_sync(vit_engine *e) {
  * the gather of the FIRST piece (nothing to overlap it with) 15 ms of a 512-image call.  The gather runs on a few OpenMP
  * threads and a piece goes up in sub-pieces of 64 images, so the H2D copy of one sub-piece overlaps the gather of the
  * next. */
-#define GATHER_THREADS 8
+#define GATHER_THREADS_MAX 16
 #define SUB_PIECE 64
+#define SUB_PIECE_FIRST 16 /* the call's first piece goes up in sub-pieces of 16: its upload starts after 10 MB of gathering */
+static int gather_threads(void) {
+    int n = omp_get_num_procs();
+    return n < 1 ? 1 : (n > GATHER_THREADS_MAX ? GATHER_THREADS_MAX : n);
+}
 static void gather_images(float *dst, const float *const *images, int first, int count, size_t img) {
-#pragma omp parallel for num_threads(GATHER_THREADS) schedule(static) if (count >= 8)
+    const int nt = gather_threads();
+#pragma omp parallel for num_threads(nt) schedule(static) if (count >= 4)
     for (int i = 0; i < count; ++i) memcpy(dst + (size_t)i * img, images[first + i], img * sizeof(float));
 }
-static int stage_piece(vit_engine *e, int slot, const float *const *images, int first, int count, size_t img) {
-    for (int s0 = 0; s0 < count; s0 += SUB_PIECE) {
-        const int c = count - s0 < SUB_PIECE ? count - s0 : SUB_PIECE;
+static int stage_piece(vit_engine *e, int slot, const float *const *images, int first, int count, size_t img, int sub) {
+    for (int s0 = 0; s0 < count; s0 += sub) {
+        const int c = count - s0 < sub ? count - s0 : sub;
         gather_images(e->pin_in[slot] + (size_t)s0 * img, images, first + s0, c, img);
         HIP_TRY(e, vithip_memcpy_h2d(e->in_stage[slot] + (size_t)s0 * img, e->pin_in[slot] + (size_t)s0 * img,
                                      (size_t)c * img * sizeof(float), e->copy_stream));
@@ -1116,7 +1124,8 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
      */
     const int chunk = chunk_limit(e);
     int first_n = n;
-    if (n >= 128) first_n = 64;
+    if (e->opt.host_first_piece > 0) first_n = e->opt.host_first_piece;
+    else if (n >= 128) first_n = 64;
     else if (n >= 64) first_n = (n + 1) / 2;
     if (first_n > chunk) first_n = chunk;
     if (first_n > n) first_n = n;
@@ -1125,7 +1134,7 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
 #define PIECE_N(i) ((PIECE_LO((i) + 1) < n ? PIECE_LO((i) + 1) : n) - PIECE_LO(i))
     /* stage piece 0 */
     {
-        int rc0 = stage_piece(e, 0, images, 0, PIECE_N(0), img);
+        int rc0 = stage_piece(e, 0, images, 0, PIECE_N(0), img, np > 1 ? SUB_PIECE_FIRST : SUB_PIECE);
         if (rc0) return rc0;
     }
     for (int k = 0; k < np; ++k) {
@@ -1143,7 +1152,7 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
                 memcpy(probs[first + i], e->pin_out[b ^ 1] + (size_t)i * NC, NC * sizeof(float));
         }
         if (k + 1 < np) { /* slot b^1 is free again (its H2D, compute and D2H are complete): refill it */
-            rc = stage_piece(e, b ^ 1, images, PIECE_LO(k + 1), PIECE_N(k + 1), img);
+            rc = stage_piece(e, b ^ 1, images, PIECE_LO(k + 1), PIECE_N(k + 1), img, SUB_PIECE);
             if (rc) return rc;
         }
     }
