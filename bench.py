@@ -135,6 +135,22 @@ def pmc_mfma(kernel, tag, batch):
     return float(r["mfma_busy_percent"]), float(r["clock_ghz_from_gui_active"])
 
 
+def replayed_counters(kernel, tag, batch):
+    """Counter-derived fields of a roofline object for `kernel` (HBM bytes per launch, MFMA-busy %, clock) from the committed
+    rocprofv3 passes of profiles/<round>/, with their provenance: they cannot be read without the profiler, so they are REPLAYED
+    from another run of the same command (possibly another device of the pool) and marked `live: false`; everything else in
+    the object they join is measured live in the process that prints it."""
+    traffic, traffic_src = pmc_traffic(kernel, tag, batch)
+    busy, clock = pmc_mfma(kernel, tag, batch)
+    replayed = None
+    if traffic_src or busy is not None:
+        replayed = dict(traffic_src or {"path": os.path.join("profiles", PROFILE_ROUND, f"mfma_util_{tag}.csv")},
+                        fields=[k for k, v in (("traffic", traffic), ("mfma_busy_percent_rocprof", busy),
+                                               ("clock_ghz_rocprof", clock)) if v is not None],
+                        live=False)
+    return {"traffic": traffic, "mfma_busy_percent_rocprof": busy, "clock_ghz_rocprof": clock, "replayed_from": replayed}
+
+
 def clock_limit_probe(binding, torch, dev, cfg, batch, dtype):
     """The same GEMM launch (the dominant kernel's shape, product library, default stream) on random and on all-zero operands:
     identical instructions and memory traffic, different bit activity.  The chip runs these kernels at the clock its power limit
@@ -311,7 +327,8 @@ def other_config(pkg, binding, torch, np, dev, device_index, config, weights=Non
             "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "lanes_per_gpu": lanes,
             "setup_seconds": round(setup_s, 2),
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 4),
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), **replayed_counters(dom_name, profile_tag(dtype, model), B),
+                         "avg_launch_ms": round(avg_ms, 4),
                          "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
                          "whole_model_tflops": round(tflops, 2), "whole_model_frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4),
                          "stage_ms_per_step": {s_: round(r["ms"], 3) for s_, r in times["stages"].items()}},
@@ -530,21 +547,10 @@ def main() -> None:
     peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
     dom_name, dom, avg_ms, achieved, gemm_ms, gemm_flop = dominant_kernel(times, cfg, B, args.dtype, kernel_steps, saved, fold=args.ln_fold >= 0 and cfg.embed_dim % 64 == 0)
     tag = profile_tag(args.dtype, args.model)
-    traffic, traffic_src = pmc_traffic(dom_name, tag, B)
-    busy, clock = pmc_mfma(dom_name, tag, B)
-    replayed = None
-    if traffic_src or busy is not None:
-        # counter-derived fields cannot be read without the profiler: they are REPLAYED from the committed rocprofv3
-        # passes of this same command (another run, possibly another device of the pool) -- everything else in this
-        # object is measured live in this process
-        replayed = dict(traffic_src or {"path": os.path.join("profiles", PROFILE_ROUND, f"mfma_util_{tag}.csv")},
-                        fields=[k for k, v in (("traffic", traffic), ("mfma_busy_percent_rocprof", busy),
-                                               ("clock_ghz_rocprof", clock)) if v is not None],
-                        live=False)
+    counters = replayed_counters(dom_name, tag, B)
     roofline = {
         "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
-        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-        "mfma_busy_percent_rocprof": busy, "clock_ghz_rocprof": clock, "replayed_from": replayed,
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), **counters,
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
         "flop_per_launch": dom["flop"] / max(dom["launches"], 1),
         "all_gemm_tflops": round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,

@@ -43,3 +43,23 @@ def test_bench_kernel_names_match_the_profile_summaries():
     assert t and t > 0 and src["path"].endswith("hbm_traffic_pmc_f32.json")
     b, clk = bench.pmc_mfma(dom, "f32", 256)
     assert 50.0 < b <= 100.0 and 1.0 < clk < 3.0
+
+
+def test_other_configs_replay_their_counters_too():
+    """BASELINE.json configs[2] and [4] in `other_configs`: the dominant bf16 kernel's HBM bytes, MFMA-busy share and clock come from
+    the committed bf16 / ViT-L passes exactly as the headline's do, marked as replayed."""
+    bench = _load("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    rel = os.path.join(ROOT, "profiles", bench.PROFILE_ROUND)
+    for tag, batch in (("bf16", 2048), ("bf16_l16_384", 1024)):
+        assert bench.PROFILED_BATCH[tag] == batch
+        traffic = json.load(open(os.path.join(rel, f"hbm_traffic_pmc_{tag}.json")))
+        assert traffic["batch"] == batch
+        for k in ("gemm_bf16_pp_kernel<BF16>", "gemm_bf16_pp_kernel<BF16_GELU>", "gemm_bf16_pp_kernel<F32_RESIDUAL>"):
+            assert k in traffic["kernels"], (tag, k)
+        c = bench.replayed_counters("gemm_bf16_pp_kernel<F32_RESIDUAL>", tag, batch)
+        assert c["traffic"] and c["traffic"] > 1e9
+        assert 20.0 < c["mfma_busy_percent_rocprof"] <= 100.0 and 1.0 < c["clock_ghz_rocprof"] < 3.0
+        assert c["replayed_from"]["live"] is False and set(c["replayed_from"]["fields"]) == {"traffic", "mfma_busy_percent_rocprof", "clock_ghz_rocprof"}
+        assert c["replayed_from"]["path"].endswith(f"hbm_traffic_pmc_{tag}.json")
+    # a batch the passes were not collected at replays nothing
+    assert bench.replayed_counters("gemm_bf16_pp_kernel<F32_RESIDUAL>", "bf16", 512) == {"traffic": None, "mfma_busy_percent_rocprof": None, "clock_ghz_rocprof": None, "replayed_from": None}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """vit_engine_forward_host (what ViT_opencl() runs underneath, ViT_opencl.c:785-883) at the metric batch: ms per call for several
 first-piece sizes (vit_engine_options.host_first_piece), interleaved, against the device-resident forward of the same engine.
-GPU box only.    python3 tools/host_path_sweep.py [images] [first,first,...]        (0 = the engine's own choice)"""
+GPU box only.    python3 tools/host_path_sweep.py [images] [first first ...]        (0 = the engine's own choice)"""
 import importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("vision-transformer-opencl_amd")
 B = importlib.import_module("vision-transformer-opencl_amd.binding")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-firsts = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 32, 48, 64, 80, 96, 128]
+firsts = [int(a) for a in sys.argv[2:]] if len(sys.argv) > 2 else [0, 32, 48, 64, 80, 96, 128]
 cfg = pkg.VIT_B16
 W = pkg.synth.make_weights(cfg, 1234)
 imgs = pkg.synth.make_images(cfg, n, 99)

@@ -41,6 +41,7 @@ namespace vitattn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD = 64;            // head_dim
 constexpr int ROWB = HD * 4;      // bytes of one K or V row in LDS
@@ -143,12 +144,18 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
         const int img = item / heads, head = item - img * heads;
         return qkv + (size_t)img * tokens * ld + head * HD;
     };
+    // Q rows through a buffer descriptor on the head's (scalar) base and ONE 32-bit lane offset, recomputed from the lane id at every
+    // call: as 64-bit per-lane pointers the two blocks' row addresses were loop-invariant register pairs that the allocator spilled in
+    // the two-block role, and the reload's vmcnt(0) sat between the two blocks' loads -- an exposed round trip per item (round 5).
     auto load_q = [&](const float *base, int blk, f32x4 (&qf)[4]) __attribute__((always_inline)) {
-        int qrow = blk * 16 + n;
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        int qrow = blk * 16 + (lane_l & 15);
         qrow = qrow < tokens ? qrow : tokens - 1;  // rows past the end: clamped address, never stored
-        const float *src = base + (size_t)qrow * ld + 4 * g;
+        const int voff = (qrow * ld + 4 * (lane_l >> 4)) * 4;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const f32x4 *>(src + 16 * c);
+        for (int c = 0; c < 4; ++c) qf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, voff + 64 * c, 0, 0));
     };
 
     // per-lane LDS offsets
@@ -265,17 +272,24 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // Output rows: buffer stores on the image's (scalar) base with one 32-bit lane offset, recomputed per call (see load_q: the
+    // 64-bit row pointer was the last spilled value of the two-block role, reloaded behind a vmcnt(0) right after the next item's Q
+    // loads had been issued).  Everything that varies goes into the LANE offset and the immediate: for a 16-byte buffer store with
+    // a register in soffset hipcc pads no wait state in front of a write of the data registers (tools/check_inline_asm.py rule iv).
     auto store_rows = [&](int w, int blk, const f32x4 (&o)[4], float scale) __attribute__((always_inline)) {
-        const int row = blk * 16 + n;
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int row = blk * 16 + (lane_l & 15);
         if (row < q_rows) {
             const int item = w / parts;
             const int img = item / heads, head = item - img * heads;
-            float *dst = out + ((size_t)img * tokens + row) * D + head * HD + 16 * g;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)img * tokens * D, 0, tokens * D * 4, 0x00020000);
+            const int voff = (row * D + head * HD + 16 * (lane_l >> 4)) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 w;
                 w[0] = o[0][i] * scale; w[1] = o[1][i] * scale; w[2] = o[2][i] * scale; w[3] = o[3][i] * scale;
-                *reinterpret_cast<f32x4 *>(dst + 4 * i) = w;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ro, voff + 16 * i, 0, 0);
             }
         }
     };
@@ -341,13 +355,20 @@ __global__ __launch_bounds__(RES_THREADS) void attention_f32_resident_kernel(con
     // with two (t & 3 = w0, 2 + w0), one for V.  Rows past the last token are not zero-filled here but CLAMPED to the last
     // token (its values are finite, the keys are masked / weigh 0): no bounds check involved, and only the last groups pay
     // per-lane arithmetic.
+    // The three lane offsets are recomputed from the lane id at every call (half a dozen VALU instructions): kept across the
+    // item loop they were what the allocator spilled (256 VGPRs, 5-7 spilled in the metric instantiation), and a spill reload
+    // is a vector load the compiler waits for with vmcnt(0) -- here in the middle of the DMA issue, i.e. the issuing wave sat out
+    // the round trip of the pieces it had just issued, two or three times per phase (round 5).
     const int w0 = dma4 ? (wave & 3) : (wave & 1);
-    const int lane_row = row_in * ld * 4;
-    const int koffA = lane_row + ((cpos ^ (w0 << 2 | row_in)) << 4);
-    const int koffB = lane_row + ((cpos ^ ((2 + w0) << 2 | row_in)) << 4);
-    const int voffV = lane_row + (cpos << 4);
     auto dma_nd = [&](auto nd_c, const float *head_base, char *dst, bool swizzle) __attribute__((always_inline)) {
         constexpr int ND = decltype(nd_c)::value;
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));  // opaque: nothing below is loop-invariant to the compiler
+        const int row_in = lane_l >> 4, cpos = lane_l & 15;
+        const int lane_row = row_in * ld * 4;
+        const int koffA = lane_row + ((cpos ^ (w0 << 2 | row_in)) << 4);
+        const int koffB = lane_row + ((cpos ^ ((2 + w0) << 2 | row_in)) << 4);
+        const int voffV = lane_row + (cpos << 4);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int k = 0; k < (NKT * 4 + ND - 1) / ND; ++k) {
