@@ -1116,15 +1116,20 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
      * Pieces of up to max_batch images flow through two staging slots: while the GPU computes piece i,
      * the host gathers the separately allocated images of piece i+1 into pinned memory and the copy
      * stream uploads them; the results of piece i-1 are scattered to the caller's rows meanwhile.
-     * Nothing overlaps the gather + upload of the FIRST piece, so it is a small one -- 64 images: the GPU starts after 39 MB
-     * instead of half the call, and the rest arrives behind its compute in pieces as large as the workspace allows (large
-     * pieces keep the GEMMs' tile walks long).  Measured through this entry at 256 images (one device, interleaved): first piece
-     * 128 (round 2: two halves) 71.7 ms, 96 71.0, 64 69.7, 48 70.3, 32 72.5 (its GEMMs fall into the small-batch tiles), 16 71.0;
-     * 1,024 images: 64 271.0 ms, 128 272.7.  Rows are bit-identical whatever the cut.
+     * Nothing overlaps the gather + upload of the FIRST piece, so it is a small one, uploaded in sub-pieces of 16 images (the copy
+     * of one overlaps the gather of the next), and the rest arrives behind its compute in pieces as large as the workspace allows
+     * (large pieces keep the GEMMs' tile walks long).  Rows are bit-identical whatever the cut.
      */
     const int chunk = chunk_limit(e);
+    /* Round 5: what the first piece has to do is cover, with its compute, the gather + upload of the piece behind it -- and nothing
+     * more, because a small piece computes badly (ViT-B/16 fp32, device-resident: 8 images run at 56 % of the 256-image rate per
+     * image, 40 at 86 %, 64 at 90 %, 192 at 99.5 %: tools/batch_time_sweep.py).  fp32: an image is uploaded in ~13 us (602 KB at
+     * ~45 GB/s) and computed in ~400 us at small batch, so n / 21 images suffice; measured at 256 images (tools/host_path_sweep.py,
+     * ms per call, device-resident 64.9): first piece 8: 69.3 (too small: the GPU waits for the second piece), 12: 67.7, 16: 68.7,
+     * 40: 68.0, 64: 68.8 (the round-4 choice), 128: 71.2.  The bf16 engines compute an image in a tenth of that: they keep 64. */
     int first_n = n;
     if (e->opt.host_first_piece > 0) first_n = e->opt.host_first_piece;
+    else if (e->opt.dtype == VIT_DTYPE_F32 && n >= 64) first_n = ((n + 20) / 21 + 3) & ~3;
     else if (n >= 128) first_n = 64;
     else if (n >= 64) first_n = (n + 1) / 2;
     if (first_n > chunk) first_n = chunk;
