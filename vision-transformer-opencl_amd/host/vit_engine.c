@@ -1129,7 +1129,7 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
      * 40: 68.0, 64: 68.8 (the round-4 choice), 128: 71.2.  The bf16 engines compute an image in a tenth of that: they keep 64. */
     int first_n = n;
     if (e->opt.host_first_piece > 0) first_n = e->opt.host_first_piece;
-    else if (e->opt.dtype == VIT_DTYPE_F32 && n >= 64) first_n = ((n + 20) / 21 + 3) & ~3;
+    else if (e->opt.dtype == VIT_DTYPE_F32 && n >= 64) first_n = (n / 21 + 2) & ~3; /* 256 -> 12, 512 -> 24 */
     else if (n >= 128) first_n = 64;
     else if (n >= 64) first_n = (n + 1) / 2;
     if (first_n > chunk) first_n = chunk;
