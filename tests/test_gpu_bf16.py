@@ -169,6 +169,28 @@ def test_attention_bf16_streamed_reference_maximum_moves(oracle, T, qs):
     assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 4e-3).all(), float(np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("qs", [False, True], ids=["plain-q", "qscaled"])
+@pytest.mark.parametrize("T,heads,n", [(577, 16, 40), (300, 3, 200), (231, 1, 700)])
+def test_attention_bf16_streamed_head_switch_is_bit_identical_to_single_head_launches(T, heads, n, qs):
+    """The streamed kernel's head switch (round 5): a workgroup that walks SEVERAL (image, head) items retires a query block inside the
+    head's last step -- stores, state reset, the next head's Q refill -- and proves with COUNTED vmcnt waits that the refills have
+    landed (the count assumes a fixed order of the wave's vector-memory operations).  A launch of one image has at most `heads` items:
+    every workgroup takes the first-item path, which waits for everything.  Both must give the same bits for every image, on shapes
+    where a wave owns three, two and one query blocks (19, 10, 8 blocks over 8 waves), with 2.5 / 2.3 / 2.7 items per workgroup so
+    that first, middle and last heads of a walk all occur; twice, for run-to-run determinism of the walk."""
+    D = heads * 64
+    rng = np.random.default_rng(11)
+    vals = rng.uniform(-1.5, 1.5, (n * T, 3 * D)).astype(np.float32)
+    if qs:
+        vals[:, :D] *= np.float32(B.QSCALE)
+    bits = B.to_bf16_bits(vals)
+    whole = B.attention_bf16io(bits, n, T, heads, q_scaled=qs).reshape(n, T, D)
+    assert np.array_equal(B.attention_bf16io(bits, n, T, heads, q_scaled=qs).reshape(n, T, D), whole)
+    for i in list(range(0, n, max(1, n // 12))) + [n - 1]:                        # a dozen images spread over the walk, and the last
+        one = B.attention_bf16io(bits[i * T:(i + 1) * T], 1, T, heads, q_scaled=qs).reshape(T, D)
+        assert np.array_equal(whole[i], one), i
+
+
 BF16_PROB_TOL = 2e-2   # bf16 activations carry 8 significant bits; the fp32 bar (1e-4) does not apply here
 
 

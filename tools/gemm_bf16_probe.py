@@ -12,7 +12,7 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 M = batch * 197
 SHAPES = {"qkv": (M, 2304, 768, 0), "outproj": (M, 768, 768, 2), "fc1": (M, 3072, 768, 1), "fc2": (M, 768, 3072, 2)}
 if len(sys.argv) > 2 and sys.argv[2] == "probe":  # timing-only builds on the qkv shape: 101 = no DMA in loop, 102 = DMA only
-    SHAPES = {"qkv": (M, 2304, 768, 0), "pp_no_dma": (M, 2304, 768, 201), "pp_no_mfma": (M, 2304, 768, 202), "pp_no_reads": (M, 2304, 768, 203), "pp_no_epilogue": (M, 2304, 768, 204), "pp_K3072": (M, 2304, 3072, 0), "pp_K3072_no_epi": (M, 2304, 3072, 204),
+    SHAPES = {"qkv": (M, 2304, 768, 0), "fc1": (M, 3072, 768, 1), "fc1_shape_no_epilogue": (M, 3072, 768, 204), "fc1_shape_bias_only": (M, 3072, 768, 0), "pp_no_dma": (M, 2304, 768, 201), "pp_no_mfma": (M, 2304, 768, 202), "pp_no_reads": (M, 2304, 768, 203), "pp_no_epilogue": (M, 2304, 768, 204), "pp_K3072": (M, 2304, 3072, 0), "pp_K3072_no_epi": (M, 2304, 3072, 204),
               "qkv_no_dma": (M, 2304, 768, 101), "qkv_dma_only": (M, 2304, 768, 102)}
 rng = np.random.default_rng(0)
 for name, (M_, N, K, epi) in SHAPES.items():
