@@ -81,13 +81,9 @@ constexpr float kScaleS = 0.125f * 1.4426950408889634f;
 #ifndef ST_PRIO
 #define ST_PRIO 0
 #endif
-// ST_INTERLEAVE: the score MFMAs of the NEXT unit are issued between the exponentials of the current one, two per eight v_exp_f32,
-// instead of as a burst of eight in front of the softmax: a wave issues in order, so a burst keeps it out of its own VALU work for
-// 8 x 32 cycles, while an MFMA placed between vector instructions runs in their shadow (it holds the issue port for 8 of its 32
-// cycles).  Same operations, same operands, same order of every accumulation: the bits do not change.
-#ifndef ST_INTERLEAVE
-#define ST_INTERLEAVE 1
-#endif
+// Tried on top of this structure and measured (profiles/r05/experiments/attention_stream_ab.jsonl): priority for the waves with the most
+// query blocks instead (the same as none); the NEXT unit's score MFMAs issued between the exponentials of the current one, two per
+// eight v_exp_f32, pinned with opaque asm -- same bits, 2.47 against 2.31 ms per launch: the burst in front of the softmax is faster.
 #ifdef VIT_PROBES
 unsigned long long *g_stream_dbg = nullptr;
 #endif
@@ -336,29 +332,21 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 
         f32x16 st[2][SUB];  // two score buffers
         [[maybe_unused]] float m_init[2] = {0.0f, 0.0f};  // QS: the reference the buffer's accumulators were initialised with (finite)
-        // A scores job = (buffer, block, sub-chunk): begin (accumulator start, first fragments) and four k-steps of two MFMAs each.
-        // scores() runs a job as one burst; softmax_pv() below can carry the NEXT unit's job between its exponentials.
-        // The job's fragments are single-buffered (12 registers: one Q fragment, two K fragments): the reads for k-step ks + 1 are
-        // issued right behind the MFMAs of k-step ks and have the eight exponentials in between (or, in a burst, nothing) to land.
-        bf16x8 jq, jk[SUB];
-        int jfrag = 0;
-        const bf16_t *jqblk = Qs;
-        auto scores_reads = [&](int k0, int ks) __attribute__((always_inline)) {
-            jq = *reinterpret_cast<const bf16x8 *>(jqblk + (jfrag ^ (ks << 4)));
-#pragma unroll
-            for (int u = 0; u < SUB; ++u) jk[u] = *reinterpret_cast<const bf16x8 *>(Ks + (k0 + u) * (32 * SHD) + (jfrag ^ (ks << 4)));
-        };
-        auto scores_begin = [&](int buf, int b, int k0) __attribute__((always_inline)) {
+        // scores of sub-chunk k0 of block b -> buffer `buf`.  A sub-chunk is always computed whole: keys past `valid` (a
+        // chunk of 3 tiles, the end of the sequence) hold older, finite data in LDS and are masked to -inf below.
+        auto scores = [&](int buf, int b, int k0) __attribute__((always_inline)) {
             // Row r of a 32-row block (Q or K alike) at r * 128 B, its 16-byte chunk c at position c ^ ((r >> 1) & 7); k-step ks
             // wants chunk 2 ks + h, i.e. position ((h ^ sw) ^ 2 ks): ONE lane register and an XOR per k-step.  Recomputed from the
             // lane id here: kept across the unit's softmax these addresses were what the allocator spilled.
             int lane_l = lane;
             asm volatile("" : "+v"(lane_l));
             const int rr = lane_l & 31, hh = lane_l >> 5;
-            jfrag = rr * SHD + (((hh ^ (rr >> 1)) & 7) << 3);  // bf16 elements
-            if (first && k0 == 0 && b > 0 && b < nb_wave) wait_vm((nb_wave - 1 - b) * (ST_QDMA + ST_STORES) + ncd);  // block b's Q has landed
-            const int qb = wave + ST_WAVES * b;
-            jqblk = Qs + (qb < nblk ? qb : nblk - 1) * (32 * SHD);  // (a job on a block this wave does not own reads the last block there is)
+            const int frag_l = rr * SHD + (((hh ^ (rr >> 1)) & 7) << 3);  // bf16 elements
+            if (first && k0 == 0 && b > 0) wait_vm((nb_wave - 1 - b) * (ST_QDMA + ST_STORES) + ncd);  // block b's Q has landed
+            const bf16_t *qblk = Qs + (wave + ST_WAVES * b) * (32 * SHD);
+            bf16x8 qf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qblk + (frag_l ^ (ks << 4)));
             float init = 0.0f;
             if constexpr (QS) {
                 const float mr = m_run[b];
@@ -369,33 +357,31 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             for (int u = 0; u < SUB; ++u)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) st[buf][u][v] = init;
-            scores_reads(k0, 0);
-        };
-        auto scores_ks = [&](int buf, int k0, int ks) __attribute__((always_inline)) {
-            __builtin_amdgcn_sched_barrier(0);
+            // K fragments are read one k-step AHEAD of the MFMAs that use them (two register sets): left to itself hipcc issues
+            // read - wait - MFMA for every instruction, i.e. every MFMA pays an LDS round trip
+            bf16x8 kf[2][SUB];
+            auto read_k = [&](int ks, int set) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < SUB; ++u)  // the SUB tiles are independent accumulation chains
-                st[buf][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(jk[u], jq, st[buf][u], 0, 0, 0);
-            if (ks + 1 < 4) scores_reads(k0, ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // scores of sub-chunk k0 of block b -> buffer `buf`.  A sub-chunk is always computed whole: keys past `valid` (a
-        // chunk of 3 tiles, the end of the sequence) hold older, finite data in LDS and are masked to -inf below.
-        auto scores = [&](int buf, int b, int k0) __attribute__((always_inline)) {
-            scores_begin(buf, b, k0);
+                for (int u = 0; u < SUB; ++u)
+                    kf[set][u] = *reinterpret_cast<const bf16x8 *>(Ks + (k0 + u) * (32 * SHD) + (frag_l ^ (ks << 4)));
+            };
+            read_k(0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) scores_ks(buf, k0, ks);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) read_k(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < SUB; ++u)  // the SUB tiles are independent accumulation chains
+                    st[buf][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][u], qf[ks], st[buf][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         // online softmax of buffer `buf` (running max m, running sum l, O rescaled by 2^((m_old - m_new) c) when m moved),
         // then O^T += V^T . P^T
-        // nx_c: the next unit's scores job (nbuf, nblk_, nk0) rides between this unit's exponentials (ST_INTERLEAVE); compile-time,
-        // a run-time flag would put a branch behind every eighth exponential
-        auto softmax_pv = [&](int buf, int b, int k0, auto nx_c, int nbuf, int nblk_, int nk0) __attribute__((always_inline)) {
-            constexpr bool nx = decltype(nx_c)::value;
-            if constexpr (nx) scores_begin(nbuf, nblk_, nk0);  // its LDS reads land under the maximum and the decision below
+        auto softmax_pv = [&](int buf, int b, int k0) __attribute__((always_inline)) {
             if ((k0 + SUB) * 32 > valid) {  // wave-uniform: the sub-chunk reaches past the valid keys
                 int h4l = h4;
-                asm volatile("" : "+v"(h4l));  // opaque: the 32 key indices below are made HERE, in the rare branch, not hoisted (and spilled) as 64 loop invariants
+                asm volatile("" : "+v"(h4l));  // opaque: the key indices below are made HERE, in the rare branch, not hoisted as 64 loop invariants
 #pragma unroll
                 for (int u = 0; u < SUB; ++u)
 #pragma unroll
@@ -445,19 +431,6 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                         const float e = __builtin_amdgcn_exp2f(st[buf][u][v]);  // exp2(-inf) = 0: masked keys
                         st[buf][u][v] = e;
                         if constexpr (!MSUM) s4[v & 3] += e;
-                        if constexpr (nx) {
-                            if ((v & 7) == 7) {  // two MFMAs of the next unit per eight exponentials
-                                // The exponentials are pure: nothing orders them against the job's MFMAs (sched_barrier constrains the
-                                // machine scheduler, and the values' only users sit far below, in P.V) -- left alone all 32 end up behind
-                                // the job.  The empty asm makes this tile's registers opaque HERE: the eight values above are computed in
-                                // front of it, the job's two MFMAs follow it, and what the second asm touches (the tile the next eight
-                                // exponentials read) cannot be exponentiated before them.
-                                asm volatile("" : "+v"(st[buf][u]));
-                                scores_ks(nbuf, nk0, 2 * u + (v >> 3));
-                                if (v == 15 && u + 1 < SUB) asm volatile("" : "+v"(st[buf][u + 1]));
-                                else asm volatile("" : "+v"(st[buf][u]));
-                            }
-                        }
                     }
                 if constexpr (!MSUM) sum2 = f32x2{s4[0] + s4[1], s4[2] + s4[3]};
             } else {
@@ -473,14 +446,6 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                         st[buf][u][v] = e[0];
                         st[buf][u][v + 1] = e[1];
                         sum2 += e;
-                        if constexpr (nx) {
-                            if ((v & 7) == 6) {
-                                asm volatile("" : "+v"(st[buf][u]));
-                                scores_ks(nbuf, nk0, 2 * u + (v >> 3));
-                                if (v == 14 && u + 1 < SUB) asm volatile("" : "+v"(st[buf][u + 1]));
-                                else asm volatile("" : "+v"(st[buf][u]));
-                            }
-                        }
                     }
             }
             if (__any(m_new != m_old)) {  // wave-uniform: most sub-chunks leave every row's maximum where it was
@@ -512,7 +477,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                 lsum[0] = l_run[b];
             }
             int lane_v = lane;
-            asm volatile("" : "+v"(lane_v));  // the V^T fragment addresses are made per unit, not kept (and spilled) across the step
+            asm volatile("" : "+v"(lane_v));  // the V^T fragment addresses are made per unit, not kept across the step
             auto read_v = [&](int g, int set) __attribute__((always_inline)) {  // g = 2 u + s2
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) vf[set][dt] = v_frag_tr(Vs, (k0 + (g >> 1)) * 32 + 16 * (g & 1), dt, lane_v);
@@ -544,46 +509,23 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 
         // pipeline over this wave's blocks (wave, wave + 8, wave + 16: contiguous in b)
         if (wave < nblk) scores(0, 0, 0);
-        if (dma_late && next_item >= 0) dma_chunk(next_item, next_ch, slot ^ 1);  // (in front of everything the waits count)
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
             if (wave + ST_WAVES * b >= nblk) continue;  // wave-uniform
-            [[maybe_unused]] const bool more = b + 1 < MAXB && wave + ST_WAVES * (b + 1) < nblk;  // this wave has a next block
-            constexpr std::true_type yes{};
-            constexpr std::false_type no{};
-            if constexpr (ST_INTERLEAVE) {
-                // unit (b, 0) carries the scores of (b, SUB) -- or, in a chunk of one sub-chunk, of the next block's first unit;
-                // unit (b, SUB) carries the next block's first scores
-                // A wave WITHOUT a next block still carries a job behind its last unit (the b + 1 < MAXB test folds at compile time, so
-                // only the third block ends without one): the scores of a block this wave does not own, from the last Q block there is,
-                // into a buffer nobody reads -- eight MFMAs in the exponentials' shadow cost less than a second copy of the unit's code
-                // with no job in it, whose join with this one is what the register allocator spilled on (169 VGPRs).
-                // (Every chunk of this kernel has a second sub-chunk: at least eight key tiles in chunks of at most four make every
-                // chunk three or four tiles long, and the sequence's last tile holds at least one key -- `two` is always true here;
-                // the launcher checks the tile count.)
-                const int nb1 = b + 1 < MAXB ? b + 1 : b;
-                softmax_pv(0, b, 0, yes, 1, b, SUB);
-                if (b + 1 < MAXB) softmax_pv(1, b, SUB, yes, 0, nb1, 0);
-                else softmax_pv(1, b, SUB, no, 0, 0, 0);
-                if (last) retire_block(b);
-            } else {
-                if (two) scores(1, b, SUB);                 // in the matrix pipe while the softmax below runs on the VALU
-                softmax_pv(0, b, 0, no, 0, 0, 0);
-                if (last && !two) retire_block(b);
-                if (more) scores(0, b + 1, 0);              // the next block's first scores
-                if (two) softmax_pv(1, b, SUB, no, 0, 0, 0);
-                if (last && two) retire_block(b);
-            }
+            if (two) scores(1, b, SUB);                 // in the matrix pipe while the softmax below runs on the VALU
+            softmax_pv(0, b, 0);
+            if (b == 0 && dma_late && next_item >= 0) dma_chunk(next_item, next_ch, slot ^ 1);  // (in front of everything the waits count)
+            if (last && !two) retire_block(b);
+            if (b + 1 < MAXB && wave + ST_WAVES * (b + 1) < nblk) scores(0, b + 1, 0);  // the next block's first scores
+            if (two) softmax_pv(1, b, SUB);
+            if (last && two) retire_block(b);
         }
     };
 
     int item = blockIdx.x;
     if (item >= n_items) return;  // workgroup-uniform
     const int stride = gridDim.x;
-    // ST_PRIO 1: static priority for the second-dispatched half (T5's static form; measured worse: 2.33 against 2.22 ms).
-    // ST_PRIO 2: static priority for the waves that own the MOST query blocks (the step's critical path): measured the same as none.
-    if (ST_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if (ST_PRIO == 2 && nblk > ST_WAVES && (nblk - 1 - wave) / ST_WAVES == (nblk - 1) / ST_WAVES && (nblk % ST_WAVES) != 0) __builtin_amdgcn_s_setprio(1);
+    if (ST_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses the issue arbitration otherwise (T5, static form)
     // the ring starts zeroed: stale rows that a partial sub-chunk multiplies by 0 must be finite from the first step on
     for (int i = tid; i < 2 * SBUF / 8; i += ST_THREADS) reinterpret_cast<uint4 *>(lds)[i] = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
