@@ -1121,16 +1121,20 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
      * (large pieces keep the GEMMs' tile walks long).  Rows are bit-identical whatever the cut.
      */
     const int chunk = chunk_limit(e);
-    /* Round 5: what the first piece has to do is cover, with its compute, the gather + upload of the piece behind it -- and nothing
-     * more, because a small piece computes badly (ViT-B/16 fp32, device-resident: 8 images run at 56 % of the 256-image rate per
-     * image, 40 at 86 %, 64 at 90 %, 192 at 99.5 %: tools/batch_time_sweep.py).  fp32: an image is uploaded in ~13 us (602 KB at
-     * ~45 GB/s) and computed in ~400 us at small batch, so n / 21 images suffice; measured at 256 images (tools/host_path_sweep.py,
-     * ms per call, device-resident 64.9): first piece 8: 69.3 (too small: the GPU waits for the second piece), 12: 67.7, 16: 68.7,
-     * 40: 68.0, 64: 68.8 (the round-4 choice), 128: 71.2.  The bf16 engines compute an image in a tenth of that: they keep 64. */
+    /* Round 5: what the first piece has to do is cover, with its compute, the gather + upload of the piece behind it -- and no
+     * more than that, because a small piece computes badly (ViT-B/16 fp32, device-resident: 8 images run at 56 % of the 256-image
+     * rate per image, 40 at 86 %, 64 at 90 %, 192 at 99.5 %: tools/batch_time_sweep.py).  Measured at 256 images
+     * (tools/host_path_sweep.py, ms per call, device-resident 64.9): first piece 8: 69.3 (the GPU waits for the second piece),
+     * 12: 67.7, 16: 68.7, 40: 68.0, 64: 68.8 (the round-4 choice), 128: 71.2 -- on a box whose host gathers at ~40 GB/s.  On
+     * one that gathers at ~16 GB/s the 12-image piece left the GPU idle for 4 ms (71.2 ms per call): the choice is 5 n / 32
+     * (40 of 256, at most 64), whose compute covers the next piece's staging down to ~11 GB/s.  The bf16 engines compute an
+     * image in a tenth of the time: they keep 64. */
     int first_n = n;
     if (e->opt.host_first_piece > 0) first_n = e->opt.host_first_piece;
-    else if (e->opt.dtype == VIT_DTYPE_F32 && n >= 64) first_n = (n / 21 + 2) & ~3; /* 256 -> 12, 512 -> 24 */
-    else if (n >= 128) first_n = 64;
+    else if (e->opt.dtype == VIT_DTYPE_F32 && n >= 128) {
+        first_n = (5 * n / 32 + 2) & ~3;
+        if (first_n > 64) first_n = 64;
+    } else if (n >= 128) first_n = 64;
     else if (n >= 64) first_n = (n + 1) / 2;
     if (first_n > chunk) first_n = chunk;
     if (first_n > n) first_n = n;
