@@ -4,7 +4,7 @@
 # sys/hip traces); the program comes directly after `--` (no env/bash hop).  Results land in
 # gpurun_out/profiles/<round>/ -- copy them into profiles/<round>/ and commit.
 set -eo pipefail
-R=${1:-r01}
+R=${1:-r05}
 OUT=gpurun_out/profiles/$R
 W=gpurun_out/prof_work
 rm -rf "$W" "$OUT"; mkdir -p "$W" "$OUT"
