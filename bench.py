@@ -75,7 +75,7 @@ def load_golden(np, model, weight_seed):
     return g["probs"].astype(np.float32), int(g["image_seed"])
 
 
-PROFILE_ROUND = "r04"   # profiles/<round>/: the committed rocprofv3 passes the replayed counter fields come from
+PROFILE_ROUND = "r05"   # profiles/<round>/: the committed rocprofv3 passes the replayed counter fields come from
 
 
 def profile_tag(dtype, model):

@@ -9,6 +9,8 @@ OUT=gpurun_out/profiles/$R
 W=gpurun_out/prof_work
 rm -rf "$W" "$OUT"; mkdir -p "$W" "$OUT"
 export TMPDIR=/tmp
+# the GPU box has no .git: `git rev-parse --short HEAD > .commit_id` before the gpurun call (the file is git-ignored and travels with the snapshot)
+export VIT_COMMIT=${VIT_COMMIT:-$(cat .commit_id 2>/dev/null || true)}
 export VIT_DEVICE=$(python3 -c "import importlib,sys; sys.path.insert(0,'.'); b=importlib.import_module('vision-transformer-opencl_amd.binding'); i=b.device_info(0); print((i['name'] or 'MI355X pool box'), '(' + i['arch'] + ',', i['compute_units'], 'CUs)')" 2>/dev/null)
 
 stats() {  # name, bench args...

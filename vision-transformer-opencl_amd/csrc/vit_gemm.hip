@@ -604,6 +604,13 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
         p.sk_ws = w->dev;
         p.sk_slots = w->slots;
         p.sk_late = a->handover_test == 1;
+        // The generation is a HOST counter baked into the launch's parameters: it numbers the launches ENQUEUED on this workspace.  A
+        // hipGraph that captured this launch replays the same number every time (vit_engine_options.use_graph), so under replay the
+        // tag does not tell one replay's words from the previous replay's -- what protects a replay is what protects every launch:
+        // each path of the hand-over leaves its flag word 0 (taken: the owner clears it; withdrawn: the helper clears it), so a
+        // COMPLETED launch leaves no word behind.  The generation only covers what that cannot: words left by a launch that was
+        // aborted mid-way (a fault, a killed process sharing nothing -- i.e. in practice never under replay either, since an aborted
+        // replay takes the graph's stream down with it).
         w->gen = w->gen >= (1 << 28) ? 1 : w->gen + 1;  // (launches on one workspace are ordered by contract: one stream, one caller)
         p.sk_gen = w->gen;
     }
