@@ -38,4 +38,5 @@ if hasattr(L, "vithip_attention_set_debug_buffer"):
     L.vithip_attention_set_debug_buffer(None)
     for w in (0, 3, 7):
         seg = np.median(d[:, w, 1:13] - d[:, w, 0:12], axis=0).astype(int)
-        print(json.dumps({"wave": w, "segments(top-barrier, then per step: compute, barrier)": seg.tolist()}))
+        print(json.dumps({"wave": w, "segments(top-barrier, then per step: compute, barrier) -- or, for a -DST_UNIT_STAMPS=1 build, the second step of item 1: "
+                          "[first score burst, second burst, max (0,0), decide+exp+sums (0,0), pack+PV (0,0), next block's burst, max (0,1), exp (0,1), PV (0,1)]": seg.tolist()}))

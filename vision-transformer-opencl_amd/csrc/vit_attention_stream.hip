@@ -131,9 +131,15 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 #ifdef VIT_PROBES
     unsigned long long ts[16] = {};
     int nts = 0, it_no = 0;
-#define ST_STAMP() do { if (dbg && it_no == 1 && nts < 16) ts[nts++] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef ST_UNIT_STAMPS
+#define ST_UNIT_STAMPS 0   // 1 (probe build, tools/build_variant.sh -DVIT_PROBES -DST_UNIT_STAMPS=1): stamps INSIDE the units of block 0 in the second step of item 1
+#endif
+    [[maybe_unused]] bool ustamp_on = false;
+#define ST_STAMP() do { if (!ST_UNIT_STAMPS && dbg && it_no == 1 && nts < 16) ts[nts++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ST_USTAMP() do { if (ST_UNIT_STAMPS && dbg && ustamp_on && nts < 16) { __builtin_amdgcn_sched_barrier(0); ts[nts++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define ST_STAMP() do { } while (0)
+#define ST_USTAMP() do { } while (0)
 #endif
     // ring: 2 x (K 16 KB + V 16 KB); behind it the Q blocks of the head (32 rows x 128 B each, swizzled like K), indexed by
     // block: a wave reads and refills only ITS blocks, so Q needs no barrier of its own
@@ -403,6 +409,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             // sub-chunk (some row of 32 nearly always finds a slightly larger score), runs a few times per head.
             constexpr float kDefer = 8.0f;
             const float m_old = m_run[b];
+            if (b == 0) ST_USTAMP();  // maximum over the unit's 32 scores done
             f32x2 sum2 = {0.0f, 0.0f};
             float m_new;
             if constexpr (QS) {
@@ -462,6 +469,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                     }
             }
             if constexpr (!MSUM) l_run[b] += sum2[0] + sum2[1];
+            if (b == 0) ST_USTAMP();  // decision, exponentials, sums, rescale done
             // P.V: the V^T fragments of 16-key group g+1 are read before the MFMAs of group g.
             // MSUM: the row sums come out of the matrix pipe too -- one more MFMA per 16-key group with an all-ones A operand gives
             // every register of `lsum` the sum of this lane's column of P over the group's 16 keys (both half-waves' keys: the
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (MSUM) l_run[b] = lsum[0];
+            if (b == 0) ST_USTAMP();  // packing + P.V done
         };
         // a block's last unit of the head is behind it: out with it, and in with the next head's Q
         auto retire_block = [&](int b) __attribute__((always_inline)) {
@@ -508,15 +517,19 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
         };
 
         // pipeline over this wave's blocks (wave, wave + 8, wave + 16: contiguous in b)
+        ST_USTAMP();  // step start (behind the ring DMA issue / the stagger)
         if (wave < nblk) scores(0, 0, 0);
+        ST_USTAMP();  // first score burst issued
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
             if (wave + ST_WAVES * b >= nblk) continue;  // wave-uniform
             if (two) scores(1, b, SUB);                 // in the matrix pipe while the softmax below runs on the VALU
+            if (b == 0) ST_USTAMP();  // second score burst issued
             softmax_pv(0, b, 0);
             if (b == 0 && dma_late && next_item >= 0) dma_chunk(next_item, next_ch, slot ^ 1);  // (in front of everything the waits count)
             if (last && !two) retire_block(b);
             if (b + 1 < MAXB && wave + ST_WAVES * (b + 1) < nblk) scores(0, b + 1, 0);  // the next block's first scores
+            if (b == 0) ST_USTAMP();  // next block's score burst issued
             if (two) softmax_pv(1, b, SUB);
             if (last && two) retire_block(b);
         }
@@ -552,6 +565,9 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             // the step after this one: the next chunk of this head, or the first chunk of the next head
             const int ni = ch + 1 < nch ? item : (next_item < n_items ? next_item : -1);
             const int nc = ch + 1 < nch ? ch + 1 : 0;
+#ifdef VIT_PROBES
+            ustamp_on = it_no == 1 && ch == 1;
+#endif
             step(slot, item, ch, ni, nc, ch == 0 && !first_item, ch == nch - 1);
             ST_STAMP();
             slot ^= 1;
@@ -574,6 +590,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     }
 #endif
 #undef ST_STAMP
+#undef ST_USTAMP
 }
 
 // 224 < tokens <= 704 (the head's Q blocks share the LDS with the K/V ring).  q_scaled: the Q columns hold 0.125 * log2(e) * q.
