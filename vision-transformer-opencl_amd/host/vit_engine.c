@@ -955,22 +955,17 @@ static int stage_head(chunk_ctx *c, float *d_probs, int *d_label, float *d_prob)
     return VIT_OK;
 }
 
-/* The forward of images [base, base + nb) of a staging buffer (d_images / d_probs / d_label / d_prob point at ITS image 0), in the
- * workspace rows of those images, on stream s.  base = 0 is the ordinary chunk.  base > 0 (vit_engine_forward_host, round 5): a
- * second, single-lane forward on another stream beside one that is still running on other rows -- every buffer of the workspace
- * is indexed by image, so the two never meet; one lane only, because lane j > 0 of a chunk lives on aux_stream[j - 1], which is
- * where such a forward itself runs. */
-static int forward_chunk_at(vit_engine *e, vithip_stream_t s, int base, const float *d_images, int nb, float *d_probs,
-                            int *d_label, float *d_prob) {
+static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images, int nb, float *d_probs,
+                         int *d_label, float *d_prob) {
     const vit_config *cfg = &e->cfg;
     chunk_ctx ctx, *c = &ctx;
     c->e = e;
     c->T = e->tokens; c->D = cfg->embed_dim; c->H = cfg->hidden_dim; c->NC = cfg->num_classes;
     c->L = e->opt.lanes > VIT_MAX_LANES ? VIT_MAX_LANES : e->opt.lanes;
-    if (c->L < 1 || nb < 2 * c->L || base > 0) c->L = 1;
+    if (c->L < 1 || nb < 2 * c->L) c->L = 1;
     for (int j = 0; j < c->L; ++j) {
-        c->lane[j].off = base + (int)((long)nb * j / c->L);
-        c->lane[j].n = base + (int)((long)nb * (j + 1) / c->L) - c->lane[j].off;
+        c->lane[j].off = (int)((long)nb * j / c->L);
+        c->lane[j].n = (int)((long)nb * (j + 1) / c->L) - c->lane[j].off;
         c->lane[j].s = j == 0 ? s : e->aux_stream[j - 1];
         c->lane[j].stats_ready = 0;
     }
@@ -1015,10 +1010,6 @@ static int forward_chunk_at(vit_engine *e, vithip_stream_t s, int base, const fl
     }
     e->last_rows = nb;
     return VIT_OK;
-}
-static int forward_chunk(vit_engine *e, vithip_stream_t s, const float *d_images, int nb, float *d_probs,
-                         int *d_label, float *d_prob) {
-    return forward_chunk_at(e, s, 0, d_images, nb, d_probs, d_label, d_prob);
 }
 #undef LANES
 #undef LN_
@@ -1091,10 +1082,7 @@ int vit_engine_sync(vit_engine *e) {
  * next. */
 #define GATHER_THREADS_MAX 16
 #define SUB_PIECE 64
-#ifndef SUB_PIECE_FIRST
-#define SUB_PIECE_FIRST 16
-#endif
-// /* the call's first piece goes up in sub-pieces of 16: its upload starts after 10 MB of gathering */
+#define SUB_PIECE_FIRST 16 /* the call's first piece goes up in sub-pieces of 16: its upload starts after 10 MB of gathering */
 static int gather_threads(void) {
     int n = omp_get_num_procs();
     return n < 1 ? 1 : (n > GATHER_THREADS_MAX ? GATHER_THREADS_MAX : n);
@@ -1150,38 +1138,6 @@ int vit_engine_forward_host(vit_engine *e, const float *const *images, int n, fl
     else if (n >= 64) first_n = (n + 1) / 2;
     if (first_n > chunk) first_n = chunk;
     if (first_n > n) first_n = n;
-    /* Round 5, fp32, one lane, a call that fits one chunk: the two pieces run BESIDE each other, not behind each other.  Both live in
-     * staging slot 0 and in their own rows of the workspace; the first goes on the engine's stream as soon as it is up, the second
-     * -- its upload and then its forward -- on a second stream while the first is computing.  What that buys is the first piece's
-     * tile quantisation: a 40-image forward fills 512 workgroups badly (86 % of the large-batch rate per image); with the second
-     * piece's launches queued beside it, their workgroups take the compute units the first piece's last rounds leave idle. */
-    if (e->opt.dtype == VIT_DTYPE_F32 && e->opt.lanes <= 1 && !e->opt.profile && n <= chunk && first_n < n && n - first_n <= e->lane_cap) {
-        const int rest = n - first_n;
-        vithip_stream_t s2 = e->aux_stream[0];
-        if (!e->gemm_ws[1]) HIP_TRY(e, vithip_gemm_f32_workspace_create(&e->gemm_ws[1]));
-        int rc = stage_piece(e, 0, images, 0, first_n, img, SUB_PIECE_FIRST);
-        if (rc) return rc;
-        HIP_TRY(e, vithip_stream_wait_event(e->stream, e->ev_h2d[0]));
-        rc = forward_chunk_at(e, e->stream, 0, e->in_stage[0], first_n, e->out_stage[0], NULL, NULL);
-        if (rc) return rc;
-        /* the second piece: gathered while the first computes, uploaded on ITS stream, in front of its own kernels */
-        for (int s0 = 0; s0 < rest; s0 += SUB_PIECE) {
-            const int cn = rest - s0 < SUB_PIECE ? rest - s0 : SUB_PIECE;
-            const size_t at = (size_t)(first_n + s0) * img;
-            gather_images(e->pin_in[0] + at, images, first_n + s0, cn, img);
-            HIP_TRY(e, vithip_memcpy_h2d(e->in_stage[0] + at, e->pin_in[0] + at, (size_t)cn * img * sizeof(float), s2));
-        }
-        rc = forward_chunk_at(e, s2, first_n, e->in_stage[0], rest, e->out_stage[0], NULL, NULL);
-        if (rc) return rc;
-        HIP_TRY(e, vithip_event_record(e->ev_join[0], s2));
-        HIP_TRY(e, vithip_stream_wait_event(e->stream, e->ev_join[0]));
-        HIP_TRY(e, vithip_memcpy_d2h(e->pin_out[0], e->out_stage[0], (size_t)n * NC * sizeof(float), e->stream));
-        HIP_TRY(e, vithip_event_record(e->ev_done[0], e->stream));
-        HIP_TRY(e, vithip_event_sync(e->ev_done[0]));
-        for (int i = 0; i < n; ++i) memcpy(probs[i], e->pin_out[0] + (size_t)i * NC, NC * sizeof(float));
-        e->last_rows = n;
-        return VIT_OK;
-    }
     const int np = 1 + (n - first_n + chunk - 1) / chunk;
 #define PIECE_LO(i) ((i) == 0 ? 0 : ((i) >= np ? n : first_n + ((i) - 1) * chunk))
 #define PIECE_N(i) ((PIECE_LO((i) + 1) < n ? PIECE_LO((i) + 1) : n) - PIECE_LO(i))
