@@ -450,9 +450,9 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
             // auto.  Large problems: the persistent walk wins where the epilogue is light on registers (bias, bias+GELU:
             // fc1 22.0 vs 23.0 ms per step); the residual epilogue needs 255 VGPRs there and is faster one tile per
             // workgroup (fc2 21.7 vs 22.5 ms).  Small problems (few rounds of 128x128 tiles over the 512 workgroup
-            // slots) are tile-quantisation-bound: 128x64 tiles double the workgroups.  Measured per stage at batch
-            // 32 / 64 / 128 (bench.py --batch B --gemm-tile 0|8): a single image 5.47 -> 3.64 ms, batch 64 +7 %; the
-            // thresholds leave every GEMM of the batch-256 metric (>= 1182 tiles per lane) on the large-problem kernels.
+            // slots) are tile-quantisation-bound: smaller tiles multiply the workgroups (rounds 1-4: 128x64 below 2,048 tiles; round 5,
+            // below: 64x64, and the walk from 1,280).  The thresholds leave every GEMM of the batch-256 metric (>= 1182 tiles per lane)
+            // on the large-problem kernels.
             const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
             // Latency regime (the reference's own use is ONE image, Main.c:45-46): when even 128x64 tiles leave CUs without
             // a workgroup, the time of a GEMM is one wave's K loop -- 2 accumulators x K/2 MFMAs of 64 cycles -- so 64x64
@@ -465,8 +465,15 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
                 return vitgemm::launch_gemm_f32_latency(stream, p, epilogue);
             if ((long)((p.M + 127) / 128) * ((p.N + 63) / 64) < 256)
                 return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);
+            // Round 5 (tools/small_batch_tiles.py: every GEMM of the ViT-B/16 forward at 12 ... 128 images on every tile code): below the
+            // persistent walk's range the 64x64 tile beats the 128x64 one at every size measured -- four times the workgroups of a
+            // 128x128 walk for the partial last round to spread over (fc2 at 48 images 4.50 -> 3.96 ms per 12 launches, out_proj 1.30 ->
+            // 1.09; at 96 images 7.93 -> 7.81 / 2.23 -> 2.11) -- and the persistent walk pays from ~1,280 tiles on, not from 2,048 (QKV at
+            // 48 images, 1,332 tiles: 3.30 -> 2.97 ms; fc1 at 40 images, 1,488 tiles: 3.70 -> 3.38).  A 40-image forward 12.6 -> ~11.9 ms,
+            // 12 images 5.2 -> 4.8: the first piece of a host call (vit_engine_forward_host) and every small batch.  Same bits on every
+            // tile, so the choice is time only.
             if (epilogue == VITHIP_EPI_BIAS_RESIDUAL) {
-                if (tiles < 1024) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
+                if (tiles < 1024) return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);
                 // with a workspace the persistent walk hands the first K-steps of the partial last round's tiles to idle
                 // workgroups (fc2 / out_proj at batch 256: 480 -> 448 steps per workgroup); without one the residual
                 // epilogue is marginally faster one tile per workgroup (fc2 21.30 vs 21.43 ms per step)
@@ -475,7 +482,7 @@ int dispatch(hipStream_t stream, GemmParams &p, int epilogue, int tile, int grou
                     return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
                 return launch_tile<128, 128, 64, 64, AMODE, 32, true>(stream, p, epilogue);
             }
-            if (tiles < 2048) return launch_tile<128, 64, 64, 32, AMODE, 32, true>(stream, p, epilogue);
+            if (tiles < 1280) return launch_tile<64, 64, 32, 32, AMODE, 32, true>(stream, p, epilogue);
             return vitgemm::launch_persistent(stream, p, epilogue, p.group_m);
         }
     }
