@@ -95,7 +95,7 @@ typedef struct {
     int M, N, K;
     int epilogue;
     /* tuning, per call (the library keeps no process-wide tuning state); 0 = auto:
-     * tile: 0 = auto (persistent walk of 128x128 tiles for problems of many tiles, 128x64 / 64x64 / 32x32 tiles as the problem
+     * tile: 0 = auto (persistent walk of 128x128 tiles from ~1,280 tiles on, 64x64 / 32x32 tiles as the problem
      *   shrinks); one software-pipelined tile per workgroup: 10 = 128x128, 6 = 128x128 with K step 16, 7 = 256x128, 8 = 128x64,
      *   11 = 64x64; 12 = 32x32 on 16x16x4 MFMA (K % 128 == 0); 9 = persistent 128x128.  All of them give the same bits.
      * group_m: tile rows per L2 group of the XCD-aware tile walk (0 = default: plain N-fastest order when N is at most 8 tiles of
