@@ -98,3 +98,27 @@ def test_the_lint_fails_on_deliberately_broken_sites(listings):
     mut = lines[:blk[0]] + [l for l in lines[blk[0]:blk[1] + 1] if "s_nop" not in l] + lines[blk[1] + 1:]
     found = lint.check_text("\n".join(mut))[0]
     assert len(found) == 1 and "LDS-DMA" in found[0], found
+
+
+def test_streamed_attention_vector_memory_operations_are_the_ones_its_counted_waits_assume(listings):
+    """csrc/vit_attention_stream.hip proves that a head's Q refills have landed with COUNTED `s_waitcnt vmcnt(N)`: N is computed from
+    ST_QDMA = 4 LDS-DMA pieces and ST_STORES = 4 output stores per retired query block, in a fixed order per wave.  That arithmetic
+    holds only while (a) every output store is one `buffer_store_dwordx4` -- 4 per block, 3 blocks, 2 copies of the retire code (chunks
+    with one / two sub-chunks) = 24 per kernel, and no other store instruction at all; (b) every load is an inline-asm LDS-DMA (no
+    register load whose wait hipcc would place itself); (c) hipcc itself waits for nothing: no `vmcnt` outside the asm blocks, no
+    scratch (a spill reload is a vector load behind a `vmcnt(0)`).  Checked on the generated assembly of both instantiations."""
+    d, r = listings
+    assert r.returncode == 0, r.stdout + r.stderr
+    lint = _lint()
+    text = open(os.path.join(d, "vit_attention_stream.s")).read()
+    kernels = [(n, b) for n, b in lint.kernels(text) if "attention_bf16_stream_kernel" in n]
+    assert len(kernels) == 2
+    src = open(os.path.join(ROOT, "vision-transformer-opencl_amd", "csrc", "vit_attention_stream.hip")).read()
+    assert "constexpr int ST_QDMA = 4, ST_STORES = 4;" in src and "constexpr int MAXB = 3;" in src
+    for name, body in kernels:
+        stores = [i for i in body if lint.VM_STORE.match(i.op)]
+        assert len(stores) == 24 and all(i.op == "buffer_store_dwordx4" and not i.in_asm for i in stores), (name, len(stores))
+        loads = [i for i in body if lint.VM_LOAD.match(i.op)]
+        assert loads and all(i.in_asm and " lds" in i.text for i in loads), name            # LDS-DMA only, all inline asm
+        assert not [i for i in body if i.op.startswith("scratch_")], name
+        assert not [i for i in body if i.op == "s_waitcnt" and "vmcnt" in i.text and not i.in_asm], name
