@@ -81,6 +81,14 @@ constexpr float kScaleS = 0.125f * 1.4426950408889634f;
 #ifndef ST_PRIO
 #define ST_PRIO 0
 #endif
+// ST_QREG: the Q fragments of a wave's first ST_QREG query blocks live in registers for the whole head (read from their LDS slot once,
+// in the head's first step) instead of being re-read for every (block, 64-key) unit -- 4 of a score burst's 12 ds_read_b128.  Round 2
+// had moved ALL of Q to LDS to make room for the second score buffer; with the step's hoisted constants gone (256 -> 211 VGPRs) all
+// three blocks' fragments fit again (247 VGPRs, no scratch).  Measured, interleaved on one device: 0 / 1 / 2 / 3 blocks = 2.322 /
+// 2.279 / 2.299 / 2.280 ms per launch at ViT-L/16-384 batch 1024 -- 1-2 %, the same bits; the LDS slots stay as the refill's landing place.
+#ifndef ST_QREG
+#define ST_QREG 3
+#endif
 // Tried on top of this structure and measured (profiles/r05/experiments/attention_stream_ab.jsonl): priority for the waves with the most
 // query blocks instead (the same as none); the NEXT unit's score MFMAs issued between the exponentials of the current one, two per
 // eight v_exp_f32, pinned with opaque asm -- same bits, 2.47 against 2.31 ms per launch: the burst in front of the softmax is faster.
@@ -244,6 +252,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     const int nblk = nkt;  // 32-row query blocks = 32-key tiles
     f32x16 o[MAXB][2];
     float m_run[MAXB], l_run[MAXB];
+    [[maybe_unused]] bf16x8 qreg[ST_QREG > 0 ? ST_QREG : 1][4];
     constexpr bool MSUM = QS && ST_MFMA_ROWSUM;  // row sums from the matrix pipe (see softmax_pv)
     const int h4 = 4 * h;
     // Q block b of this wave for `item` -> LDS (4 wave instructions of 8 rows: ST_QDMA pieces); rows past the end are clamped
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
     // last:  the item's last step -- each block is normalised, stored, re-initialised and its Q slot refilled for next_item right
     //        after its last unit.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    auto step = [&](int slot, int item, int ch, int next_item, int next_ch, bool first, bool last) __attribute__((always_inline)) {
+    auto step = [&](int slot, int item, int ch, int next_item, int next_ch, bool first, bool last, bool ch0) __attribute__((always_inline)) {
         asm volatile("" : "+s"(tk));
         const int ncd = next_item >= 0 ? chunk_dmas(next_ch) : 0;  // operations the DMA below adds in front of everything later
         const bool dma_late = ST_DMA_LATE && wave < 4;  // wave-uniform
@@ -351,8 +360,17 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
             if (first && k0 == 0 && b > 0) wait_vm((nb_wave - 1 - b) * (ST_QDMA + ST_STORES) + ncd);  // block b's Q has landed
             const bf16_t *qblk = Qs + (wave + ST_WAVES * b) * (32 * SHD);
             bf16x8 qf[4];
+            if (b < ST_QREG) {
+                if (ch0 && k0 == 0) {  // the head's first unit of this block: its Q slot -> registers, for all of the head's units
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qblk + (frag_l ^ (ks << 4)));
+                    for (int ks = 0; ks < 4; ++ks) qreg[b < ST_QREG ? b : 0][ks] = *reinterpret_cast<const bf16x8 *>(qblk + (frag_l ^ (ks << 4)));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[ks] = qreg[b < ST_QREG ? b : 0][ks];
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qblk + (frag_l ^ (ks << 4)));
+            }
             float init = 0.0f;
             if constexpr (QS) {
                 const float mr = m_run[b];
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(ST_THREADS) void attention_bf16_stream_kernel(const
 #ifdef VIT_PROBES
             ustamp_on = it_no == 1 && ch == 1;
 #endif
-            step(slot, item, ch, ni, nc, ch == 0 && !first_item, ch == nch - 1);
+            step(slot, item, ch, ni, nc, ch == 0 && !first_item, ch == nch - 1, ch == 0);
             ST_STAMP();
             slot ^= 1;
             if (ch + 1 < nch) ring_barrier();  // the next chunk has landed, everybody is done with this one
