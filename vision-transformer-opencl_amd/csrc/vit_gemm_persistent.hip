@@ -539,6 +539,10 @@ int launch_persistent_stamped(hipStream_t stream, GemmParams &p, int epilogue, i
     const dim3 grid(total < wgs ? total : wgs), block(256);
     if (epilogue == VITHIP_EPI_BIAS_GELU)
         hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, VITHIP_EPI_BIAS_GELU, true>), grid, block, 0, stream, p);
+    else if (epilogue == EPI_BIAS_GELU_LN)  // the LayerNorm fold's consumer epilogues (tools/gemm_f32_fold_stamps.py)
+        hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, EPI_BIAS_GELU_LN, true>), grid, block, 0, stream, p);
+    else if (epilogue == EPI_BIAS_LN)
+        hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, EPI_BIAS_LN, true>), grid, block, 0, stream, p);
     else
         hipLaunchKernelGGL((gemm_f32_nt_persistent_kernel<128, 128, 64, 64, VITHIP_EPI_BIAS, true>), grid, block, 0, stream, p);
     return static_cast<int>(hipGetLastError());
