@@ -112,7 +112,8 @@ typedef struct {
     int handover_test;
     /* LayerNorm folded into the GEMM behind it (both NULL = off; EPI_BIAS and EPI_BIAS_GELU only): A holds the UN-normalised
      * rows x, W and bias are the gamma- and beta-folded operands of vithip_ln_fold_weights_f32(), ln_rows [M][2] = (rstd, mean)
-     * per row of A (vithip_rowstats_f32), ln_colsum [N]; the epilogue computes
+     * per row of A (vithip_rowstats_f32), ln_colsum [N] -- or NULL when W is the CENTRED weight of
+     * vithip_ln_fold_weights_f32_centered(), whose product needs no centring (the term below is then skipped); the epilogue computes
      *     fmaf(rstd, fmaf(-mean, colsum, acc), bias) = LayerNorm(x) . W^T + b                 (ViT_seq.c:103-121 is the LayerNorm)
      * with the same two roundings in every kernel (the 32x32 kernels take the inner one as a rank-1 matrix instruction, four per
      * wave and tile: csrc/vit_gemm_common.hpp), so that the tile shapes stay bit-identical to each other.
@@ -135,6 +136,14 @@ int vithip_gemm_f32_stats_in_epilogue(const vithip_gemm_args *args);  /* 1 / 0 (
  * accumulated in double and rounded once.  W fp32 [N][K], K % 4 == 0, 16-byte aligned. */
 int vithip_ln_fold_weights_f32(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
                                float *Wf, float *colsum, float *bias_f, int N, int K);
+/* The CENTRED form of the same fold (round 5; what vit_engine uses): Wc[n][k] = gamma[k] * W[n][k] - cbar[n] with
+ * cbar[n] = sum_k gamma[k] * W[n][k] / K (sum and difference in double, one rounding per weight).  Since mean(x) = sum_k x[k] / K,
+ *     x . Wc^T = x . (gamma*W)^T - mean * colsum(gamma*W):
+ * the GEMM delivers the centred product itself and its epilogue only scales: pass Wc and bias_f with ln_rows set and
+ * ln_colsum = NULL.  residual_colsum[n] = sum_k Wc[n][k] (what the rounding of the weights left of the column sum, for the
+ * record: ~1e-7 of |W|).  Same alignment rules. */
+int vithip_ln_fold_weights_f32_centered(vithip_stream_t stream, const float *W, const float *bias, const float *gamma,
+                                        const float *beta, float *Wc, float *residual_colsum, float *bias_f, int N, int K);
 /* rows_out[m] = (rstd, mean) of x [rows][ldx], dim % 64 == 0, dim <= 2048: mean and E[x^2] - mean^2 as ViT_seq.c:103-121
  * takes them, 1 / sqrtf((double)var + 1e-6).  The sums run in ONE documented order (per 64-column strip: columns c and c + 32
  * added first, then a 32-lane butterfly 16, 8, 4, 2, 1; strips in ascending order), the order a GEMM epilogue that holds the

@@ -140,3 +140,16 @@ def test_fp32_fold_on_near_constant_rows_stays_inside_its_stated_bound():
     # and the unfolded path (LayerNorm kernel, then the plain GEMM) agrees where the statistics are well-conditioned
     unfolded = B.gemm(B.layernorm(x[:128], gamma, beta), W, b, epilogue=B.EPI_BIAS).astype(np.float64)
     assert float(np.abs(got[:128] - unfolded).max()) <= 2e-5
+    # the CENTRED weight the engine folds with since round 5 (column mean of gamma * W taken out of every row of it, no colsum term in
+    # the epilogue): the same bound with its own weight in the amplification, and the same bars
+    Wc, _, bias_c = B.ln_fold_weights_f32_centered(W, b, gamma, beta)
+    got_c = B.gemm(x, Wc, bias_c, epilogue=B.EPI_BIAS, ln=(rows, None)).astype(np.float64)
+    assert np.isfinite(got_c).all()
+    amp_c = r64[:, :1] * (np.abs(x64) @ np.abs(Wc.astype(np.float64)).T)
+    err_c = np.abs(got_c - ref)
+    assert (err_c <= 8 * 2.0 ** -24 * amp_c + 2e-5).all(), float((err_c - 8 * 2.0 ** -24 * amp_c).max())
+    worst_c = {("spread %g" % sp): float(err_c[128 * i:128 * (i + 1)].max()) for i, sp in enumerate(spreads)}
+    worst_c["constant rows (rstd 1e3)"] = float(err_c[128 * len(spreads):].max())
+    print("the same with the centred weight:", worst_c)
+    assert worst_c["spread 1"] <= 2e-5 and worst_c["spread 0.1"] <= 2e-4
+    assert float(np.abs(got_c[:128] - unfolded).max()) <= 2e-5

@@ -448,3 +448,32 @@ def test_gelu_epilogue_matches_libm_erf_over_range(oracle):
     got = B.gemm(A, W, np.zeros(32, np.float32), epilogue=B.EPI_BIAS_GELU)[:, 0]
     ref = oracle.gelu(xs)
     assert float(np.abs(got - ref).max()) <= 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(128 * 49 + 57, 2304, 768), (300, 768, 768), (128 * 30, 192, 128), (197, 3072, 768)])
+def test_gemm_layernorm_fold_with_centred_weights(M, N, K):
+    """Round 5, what the engine runs: the folded weight with its column mean taken out (vithip_ln_fold_weights_f32_centered),
+    so that  x . Wc^T = x . (gamma W)^T - mean * colsum  comes out of the GEMM itself and the epilogue only scales (ln_colsum NULL).
+    Against LayerNorm-then-GEMM (ViT_seq.c:103-121, 134-147) within the 2e-5 bar of every fp32 op test, on rows whose mean is as large
+    as their spread; every tile shape -- the kernels that skip the centring instruction and the ones that run it on a zero -- gives the
+    same bits; what is left of the weights' column sums is of the order of their rounding."""
+    x = (u(70, (M, K), 2.0) + u(71, (M, 1), 2.0)).astype(np.float32)
+    gamma, beta = (1.0 + u(72, (K,), 0.5)).astype(np.float32), u(73, (K,), 0.5)
+    W, b = u(74, (N, K), 0.05), u(75, (N,), 0.1)
+    Wc, resid, bias_f = B.ln_fold_weights_f32_centered(W, b, gamma, beta)
+    gw = gamma[None, :].astype(np.float64) * W.astype(np.float64)
+    assert np.allclose(Wc, gw - gw.mean(axis=1, keepdims=True), rtol=0, atol=2.0 ** -24 * np.abs(gw).max() * 2)
+    assert float(np.abs(resid).max()) <= K * 2.0 ** -24 * float(np.abs(gw).max())
+    _, _, bias_plain = B.ln_fold_weights_f32(W, b, gamma, beta)
+    assert np.array_equal(bias_f, bias_plain)
+    rows = B.rowstats_f32(x) if K % 64 == 0 else None
+    want = B.gemm(B.layernorm(x, gamma, beta), W, b, epilogue=B.EPI_BIAS, tile=10).astype(np.float64)
+    for epi in (B.EPI_BIAS, B.EPI_BIAS_GELU):
+        ref = B.gemm(x, Wc, bias_f, epilogue=epi, tile=10, ln=(rows, None))
+        for tile in (0, 8, 9, 11):
+            assert np.array_equal(B.gemm(x, Wc, bias_f, epilogue=epi, tile=tile, ln=(rows, None)), ref), (epi, tile)
+        assert np.array_equal(B.gemm(x, Wc, bias_f, epilogue=epi, tile=9, workspace=True, ln=(rows, None)), ref), epi
+        # a zero column sum through the centring path is the same thing, bit for bit
+        assert np.array_equal(B.gemm(x, Wc, bias_f, epilogue=epi, tile=9, ln=(rows, np.zeros(N, np.float32))), ref), epi
+    got = B.gemm(x, Wc, bias_f, epilogue=B.EPI_BIAS, ln=(rows, None)).astype(np.float64)
+    assert float(np.abs(got - want).max()) <= 2e-5

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The fp32 LayerNorm fold at the metric batch's shapes (M = 50,432), launch by launch: the consumer GEMMs (QKV, fc1) with and
-without the fold epilogue, the residual GEMMs (out_proj, fc2) with and without the row statistics in their epilogue, and the
+without the fold epilogue (the latter with the column sums subtracted in the epilogue and with the CENTRED weight that needs none),
+the residual GEMMs (out_proj, fc2) with and without the row statistics in their epilogue, and the
 passes the fold replaces or adds (LayerNorm kernel, statistics kernel, finalise).  HIP-event times, arms interleaved.  GPU box only.
 
     python3 tools/gemm_f32_fold.py [rounds]            # VIT_TOOL_ARMS="fc1,fc1 fold" to time a subset
@@ -36,15 +37,17 @@ def main():
     Wo, bo = f(D, D, a=.03), f(D, a=.1)
     W2, b2 = f(D, H, a=.02), f(D, a=.1)
 
-    def gemm(A, K, W, b, Cc, N, epi, res=None, ln=False, stats=False):
+    def gemm(A, K, W, b, Cc, N, epi, res=None, ln=False, stats=False, centred=False):
         a = B.CGemmArgs(A.ptr, K, W.ptr, K, b.ptr, res.ptr if res else None, N, Cc.ptr, N, M, N, K, epi, 0, 0, ws, 0,
-                        rows.ptr if ln else None, (cq if N == 3 * D else c1).ptr if ln else None,
+                        rows.ptr if ln else None, (cq if N == 3 * D else c1).ptr if ln and not centred else None,
                         rows.ptr if stats else None, part.ptr if stats else None)
         return lambda: B.hip_check(L.vithip_gemm_f32(None, C.byref(a)), "gemm")
 
     arms = {
         "qkv": gemm(y, D, Wq, bq, qkv, 3 * D, 0), "qkv fold": gemm(x, D, Wq, bq, qkv, 3 * D, 0, ln=True),
+        "qkv fold centred": gemm(x, D, Wq, bq, qkv, 3 * D, 0, ln=True, centred=True),
         "fc1": gemm(y, D, W1, b1, hbuf, H, 1), "fc1 fold": gemm(x, D, W1, b1, hbuf, H, 1, ln=True),
+        "fc1 fold centred": gemm(x, D, W1, b1, hbuf, H, 1, ln=True, centred=True),
         "outproj": gemm(y, D, Wo, bo, x, D, 2, res=x), "outproj stats": gemm(y, D, Wo, bo, x, D, 2, res=x, stats=True),
         "fc2": gemm(hbuf, H, W2, b2, x, D, 2, res=x), "fc2 stats": gemm(hbuf, H, W2, b2, x, D, 2, res=x, stats=True),
         "layernorm kernel": lambda: B.hip_check(L.vithip_layernorm_f32(None, x.ptr, D, y.ptr, D, g.ptr, be.ptr, M, D), "ln"),

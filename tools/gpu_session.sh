@@ -41,7 +41,7 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
 r = d["roofline"]
 print(d["value"], d["unit"], d["ms_per_step"], "ms | dominant", r["frac"], "whole", r.get("whole_model_frac"), "| stages", r.get("stage_ms_per_step"))
-for o in d.get("other_configs", []):
+for o in d.get("other_configs") or []:
     print("   ", o["workload"][:40], o["value"], o["roofline"].get("whole_model_frac"), o["roofline"].get("stage_ms_per_step"))
 if d.get("c_surface"): print("    c_surface", d["c_surface"]["value"], round(d["c_surface"]["value"] / d["value"], 4))
 PY

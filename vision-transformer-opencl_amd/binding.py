@@ -261,7 +261,8 @@ def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: i
     """C = epilogue(A . W^T + bias) through vithip_gemm_f32 (tile / group_m: per-call tuning fields, 0 = auto;
     workspace: lend the scratch that enables the helper pieces of the persistent walk; handover_test: see
     vithip_gemm_args; stats: receives the hand-over counters {"taken", "recomputed"} of the launch;
-    ln = (rows [M][2], colsum [N]): the consumer side of the LayerNorm fold, W / bias being the folded operands;
+    ln = (rows [M][2], colsum [N] or None): the consumer side of the LayerNorm fold, W / bias being the folded operands (None: the
+    CENTRED weight of ln_fold_weights_f32_centered, nothing to subtract);
     row_stats: a dict that receives "rows" = vithip_gemm_args.stats_out [M][2] and "in_epilogue" = what
     vithip_gemm_f32_stats_in_epilogue said; its key "scratch" (default True) lends stats_partials)."""
     A, W, bias = _as_f32(A), _as_f32(W), _as_f32(bias)
@@ -272,7 +273,7 @@ def gemm(A, W, bias, residual=None, epilogue=EPI_BIAS, tile: int = 0, group_m: i
     dR = DeviceArray.from_numpy(_as_f32(residual)) if residual is not None else None
     ws = gemm_workspace() if workspace else None
     dRows = DeviceArray.from_numpy(_as_f32(ln[0])) if ln is not None else None
-    dCs = DeviceArray.from_numpy(_as_f32(ln[1])) if ln is not None else None
+    dCs = DeviceArray.from_numpy(_as_f32(ln[1])) if ln is not None and ln[1] is not None else None   # None: centred weights
     dSt = DeviceArray((M, 2)) if row_stats is not None else None
     dPart = DeviceArray((max(N // 64, 1), M, 2)) if row_stats is not None and row_stats.get("scratch", True) else None
     args = CGemmArgs(dA.ptr, K, dW.ptr, K, db.ptr, dR.ptr if dR else None, N, dC.ptr, N, M, N, K, epilogue, tile, group_m, ws,
@@ -484,6 +485,19 @@ def ln_fold_weights_f32(W, bias, gamma, beta):
     lib().vithip_ln_fold_weights_f32.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int]
     hip_check(lib().vithip_ln_fold_weights_f32(None, dW.ptr, db.ptr, dg.ptr, dbe.ptr, dWf.ptr, dcs.ptr, dbf.ptr, N, K),
               "vithip_ln_fold_weights_f32")
+    return dWf.numpy(), dcs.numpy(), dbf.numpy()
+
+
+def ln_fold_weights_f32_centered(W, bias, gamma, beta):
+    """vithip_ln_fold_weights_f32_centered -> (Wc [N][K] = gamma * W - column mean, residual colsum [N], bias_f [N]): pass Wc and bias_f
+    to gemm(..., ln=(rows, None))."""
+    W, bias, gamma, beta = _as_f32(W), _as_f32(bias), _as_f32(gamma), _as_f32(beta)
+    N, K = W.shape
+    dW, db, dg, dbe = (DeviceArray.from_numpy(a) for a in (W, bias, gamma, beta))
+    dWf, dcs, dbf = DeviceArray((N, K)), DeviceArray((N,)), DeviceArray((N,))
+    lib().vithip_ln_fold_weights_f32_centered.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int]
+    hip_check(lib().vithip_ln_fold_weights_f32_centered(None, dW.ptr, db.ptr, dg.ptr, dbe.ptr, dWf.ptr, dcs.ptr, dbf.ptr, N, K),
+              "vithip_ln_fold_weights_f32_centered")
     return dWf.numpy(), dcs.numpy(), dbf.numpy()
 
 

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 1)) void gemm_f32_nt_kernel(co
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + r;
-            fold.colsum[j] = n < p.N ? p.ln_colsum[n] : 0.0f;
+            fold.colsum[j] = (p.ln_colsum && n < p.N) ? p.ln_colsum[n] : 0.0f;  // NULL: centred weights, nothing to subtract
         }
         fold.rows = reinterpret_cast<const f32x2 *>(p.ln_rows) + m0;
         fold_preload(fold, p.ln_rows, p.M, m0 + wm * WM, r, h);
@@ -624,8 +624,8 @@ int vithip_gemm_f32(vithip_stream_t stream, const vithip_gemm_args *a) {
     if (a->handover_test < 0 || a->handover_test > 1) return static_cast<int>(hipErrorInvalidValue);
     if (a->tile < 0 || (a->tile > 0 && a->tile < 6) || a->tile > 12 || a->group_m < 0 || a->group_m > 1024) return static_cast<int>(hipErrorInvalidValue);
     int epilogue = a->epilogue;
-    if (a->ln_rows || a->ln_colsum) {  // LayerNorm fold, consumer side
-        if (!a->ln_rows || !a->ln_colsum || (epilogue != VITHIP_EPI_BIAS && epilogue != VITHIP_EPI_BIAS_GELU) ||
+    if (a->ln_rows || a->ln_colsum) {  // LayerNorm fold, consumer side (ln_colsum NULL: the weight is the CENTRED one, see the header)
+        if (!a->ln_rows || (epilogue != VITHIP_EPI_BIAS && epilogue != VITHIP_EPI_BIAS_GELU) ||
             (reinterpret_cast<size_t>(a->ln_rows) & 7))
             return static_cast<int>(hipErrorInvalidValue);
         p.ln_rows = a->ln_rows;

@@ -221,17 +221,29 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
             // matrix instructions, the 16 rstd of the lane's rows (LDS reads in the persistent walk -- fetched once per block:
             // behind the scheduling fences of the GELU batches every batch would wait for its own), then the batches.
             const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7fffffff, 0x00020000);
+            // Centred weights (p.ln_colsum == NULL, vithip_ln_fold_weights_f32_centered): the accumulator IS the centred product and
+            // the block goes straight to the scaling.  (With the colsum 0 the matrix instruction below would return the accumulator bit
+            // for bit -- fma(-mean, 0, acc) -- so skipping it changes no result, in this kernel or against the ones that do not skip.)
+            // What the skip is worth is not the four instructions (0.26 % of a K = 768 tile) but where they sit: in the epilogue of one
+            // workgroup while the CU's other workgroup saturates the matrix pipe, each waits its turn and the FMAs wait for it -- stamps
+            // put the fold's epilogue at 9.5k cycles per QKV tile against 5.1k for the plain one (round 5).
+            const bool center = p.ln_colsum != nullptr;  // workgroup-uniform
             float b_op[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b_op[j] = h == 0 ? fold.colsum[j] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int lr0 = wm * WM + i * 32;
-                const float mean = fold.preloaded ? fold.mean[i] : fold.rows[lr0 + r].y;
-                const float a_op = h == 0 ? -mean : 0.0f;
                 f32x16 centered[TN];
+                if (center) {
+                    const float mean = fold.preloaded ? fold.mean[i] : fold.rows[lr0 + r].y;
+                    const float a_op = h == 0 ? -mean : 0.0f;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) centered[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op, b_op[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) centered[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op, b_op[j], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) centered[j] = acc[i][j];
+                }
                 float row_rstd[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {

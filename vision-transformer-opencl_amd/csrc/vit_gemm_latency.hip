@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_latency_kernel(const GemmPara
     [[maybe_unused]] float colsum = 0.0f;
     [[maybe_unused]] f32x2 rowpair[4] = {};
     if constexpr (EPI == EPI_BIAS_LN || EPI == EPI_BIAS_GELU_LN) {
-        colsum = n < p.N ? p.ln_colsum[n] : 0.0f;
+        colsum = (p.ln_colsum && n < p.N) ? p.ln_colsum[n] : 0.0f;  // NULL: centred weights
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int m = m0 + 16 * wm + 4 * g + v;

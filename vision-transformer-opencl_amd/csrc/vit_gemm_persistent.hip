@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_persistent_kernel(const Ge
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * WN + j * 32 + r;
-                    fold.colsum[j] = n < p.N ? p.ln_colsum[n] : 0.0f;
+                    fold.colsum[j] = (p.ln_colsum && n < p.N) ? p.ln_colsum[n] : 0.0f;  // NULL: centred weights
                 }
                 if (wave == 0) {  // the rows' pairs -> LDS (see fold_rows_lds); rows past M read as zero, never stored
                     const int left = p.M - m0 < BM ? p.M - m0 : BM;

@@ -78,7 +78,7 @@ __device__ __forceinline__ f32x2 finish_f32(float s, float ss, int dim) {
 __global__ __launch_bounds__(256) void ln_fold_weights_f32_kernel(const float *__restrict__ W, const float *__restrict__ bias,
                                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                   float *__restrict__ Wf, float *__restrict__ colsum,
-                                                                  float *__restrict__ bias_f, int N, int K) {
+                                                                  float *__restrict__ bias_f, int N, int K, int center) {
     const int lane = threadIdx.x & 63;
     const int n = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (n >= N) return;  // wave-uniform
@@ -102,6 +102,27 @@ __global__ __launch_bounds__(256) void ln_fold_weights_f32_kernel(const float *_
     for (int off = 32; off > 0; off >>= 1) {
         cs += __shfl_xor(cs, off);
         bs += __shfl_xor(bs, off);
+    }
+    if (center) {
+        // CENTRED form (vithip_ln_fold_weights_f32_centered): Wc[k] = gamma[k] W[k] - cbar, cbar = sum_k gamma[k] W[k] / K.  Then
+        //     x . Wc^T = x . (gamma W)^T - cbar * sum_k x[k] = x . (gamma W)^T - mean * colsum          (mean = sum_k x[k] / K)
+        // i.e. the GEMM itself delivers the centred product and its epilogue has nothing to subtract.  One rounding per weight (the
+        // difference is taken in double); what is left of the column sum after that rounding is written to `colsum` for the record
+        // (~K^0.5 * 2^-24 * |W|: its product with mean * rstd is 1e-6 of the output and nobody adds it).
+        const double cbar = cs / (double)K;
+        double rs = 0.0;
+        for (int c = lane * 4; c < K; c += 256) {
+            f32x4 o = *reinterpret_cast<const f32x4 *>(dst + c);   // gamma * W as stored above (this lane wrote it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (float)((double)o[j] - cbar);
+                rs += (double)o[j];
+            }
+            *reinterpret_cast<f32x4 *>(dst + c) = o;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off);
+        cs = rs;
     }
     if (lane == 0) {
         colsum[n] = (float)cs;
@@ -260,7 +281,17 @@ int vithip_ln_fold_weights_f32(vithip_stream_t stream, const float *W, const flo
         return static_cast<int>(hipErrorInvalidValue);
     if (!aligned16(W) || !aligned16(gamma) || !aligned16(beta) || !aligned16(Wf)) return static_cast<int>(hipErrorInvalidValue);
     hipLaunchKernelGGL(ln_fold_weights_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), W, bias, gamma,
-                       beta, Wf, colsum, bias_f, N, K);
+                       beta, Wf, colsum, bias_f, N, K, 0);
+    return static_cast<int>(hipGetLastError());
+}
+
+int vithip_ln_fold_weights_f32_centered(vithip_stream_t stream, const float *W, const float *bias, const float *gamma, const float *beta,
+                                        float *Wc, float *residual_colsum, float *bias_f, int N, int K) {
+    if (!W || !bias || !gamma || !beta || !Wc || !residual_colsum || !bias_f || N <= 0 || K <= 0 || K % 4)
+        return static_cast<int>(hipErrorInvalidValue);
+    if (!aligned16(W) || !aligned16(gamma) || !aligned16(beta) || !aligned16(Wc)) return static_cast<int>(hipErrorInvalidValue);
+    hipLaunchKernelGGL(ln_fold_weights_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), W, bias, gamma,
+                       beta, Wc, residual_colsum, bias_f, N, K, 1);
     return static_cast<int>(hipGetLastError());
 }
 

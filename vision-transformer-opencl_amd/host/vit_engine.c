@@ -384,8 +384,10 @@ static int fold_ln_weights(vit_engine *e) {
         float *ff = e->wfoldf + (size_t)l * (6 * D + 2 * H);
         if (e->opt.dtype == VIT_DTYPE_F32) { /* fp32 products gamma * W; sums in double, rounded once */
             float *f32 = e->wfold32 + (size_t)l * (3 * D * D + H * D);
-            HIP_TRY(e, vithip_ln_fold_weights_f32(e->stream, lw[2], lw[3], lw[0], lw[1], f32, ff, ff + 3 * D, (int)(3 * D), (int)D));
-            HIP_TRY(e, vithip_ln_fold_weights_f32(e->stream, lw[8], lw[9], lw[6], lw[7], f32 + 3 * D * D, ff + 6 * D, ff + 6 * D + H, (int)H, (int)D));
+            /* centred weights (vit_hip_kernels.h): the GEMMs deliver x . (gamma W)^T - mean * colsum themselves, their epilogues only scale;
+             * the colsum slots of wfoldf receive what the weights' rounding left of the column sums and are not read again */
+            HIP_TRY(e, vithip_ln_fold_weights_f32_centered(e->stream, lw[2], lw[3], lw[0], lw[1], f32, ff, ff + 3 * D, (int)(3 * D), (int)D));
+            HIP_TRY(e, vithip_ln_fold_weights_f32_centered(e->stream, lw[8], lw[9], lw[6], lw[7], f32 + 3 * D * D, ff + 6 * D, ff + 6 * D + H, (int)H, (int)D));
             continue;
         }
         unsigned short *f16 = e->wfold16 + (size_t)l * (3 * D * D + H * D);
@@ -527,7 +529,8 @@ static int gemm_fold(vit_engine *e, vithip_stream_t s, int stage, const float *A
     a.handover_test = e->opt.gemm_handover_test;
     a.A = A; a.lda = lda; a.W = Wf; a.ldw = K; a.bias = bias_f; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.epilogue = epi;
     a.tile = e->opt.gemm_tile; a.group_m = 0;
-    a.ln_rows = rows; a.ln_colsum = colsum;
+    (void)colsum; /* the engine's fp32 weights are the CENTRED ones (vit_engine_load_weights): nothing to subtract in the epilogue */
+    a.ln_rows = rows; a.ln_colsum = NULL;
     HIP_TRY(e, stage_begin(e, s, stage));
     HIP_TRY(e, vithip_gemm_f32(s, &a));
     HIP_TRY(e, stage_end(e, s));
