@@ -47,6 +47,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef PP_LNF_RS
 #define PP_LNF_RS 0
 #endif
+#ifndef PP_GELU_LOCKSTEP
+#define PP_GELU_LOCKSTEP 4  // pairs of the GELU epilogue advanced together: 0 (one chain after the other), 2, 4 (fc1 -1.0 % / -0.7 %, same bits)
+#endif
 constexpr int PBM = 256, PBN = 256, PBK = 64;
 constexpr int PTHREADS = 512;
 constexpr int SLOT = 128 * 128;               // one half-tile: 128 rows x 64 bf16
@@ -565,6 +568,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     bf16x8 ob;
+                    f32x2 v[4];  // the chunk's four pairs: (jj, h) = (0,0) (0,1) (1,0) (1,1)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         f32x4 t4;
@@ -573,13 +577,28 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
                         } else {
                             t4 = acc[i][2 * k + jj] + b4[2 * k + jj];
                         }
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            f32x2 v = f32x2{t4[2 * h], t4[2 * h + 1]};
-                            if constexpr (EPI == VITHIP_BF16_EPI_BF16_GELU) v = gelu_bf16_x2(v);
-                            ob[jj * 4 + 2 * h] = (__bf16)v.x;
-                            ob[jj * 4 + 2 * h + 1] = (__bf16)v.y;
+                        v[2 * jj] = f32x2{t4[0], t4[1]};
+                        v[2 * jj + 1] = f32x2{t4[2], t4[3]};
+                    }
+                    if constexpr (EPI == VITHIP_BF16_EPI_BF16_GELU) {
+#if PP_GELU_LOCKSTEP == 4
+                        gelu_bf16_lockstep<4>(v);
+#elif PP_GELU_LOCKSTEP == 2
+                        {
+                            f32x2 a[2] = {v[0], v[1]}, b[2] = {v[2], v[3]};
+                            gelu_bf16_lockstep<2>(a);
+                            gelu_bf16_lockstep<2>(b);
+                            v[0] = a[0], v[1] = a[1], v[2] = b[0], v[3] = b[1];
                         }
+#else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_bf16_x2(v[e]);
+#endif
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ob[2 * e] = (__bf16)v[e].x;
+                        ob[2 * e + 1] = (__bf16)v[e].y;
                     }
                     (k ? c1 : c0) = __builtin_bit_cast(u32x4, ob);
                 }

@@ -141,6 +141,35 @@ __device__ __forceinline__ f32x2 gelu_bf16_x2(f32x2 y) {
     return __builtin_elementwise_fma(-t, e, __builtin_elementwise_max(y, f32x2{0.f, 0.f}));
 }
 
+// The same values for NP pairs advanced TOGETHER (the scheduling fences keep hipcc from putting the chains back one after the other):
+// one pair is a chain of dependent v_pk_fma_f32, and on gfx950 a packed fma that reads the previous one's result needs a wait state --
+// hipcc fills it with `s_nop 0`, 5 per pair in the one-pair form (1,255 in the GELU kernel: a quarter of its vector issue slots beside
+// the 9 v_pk_fma_f32, 2 v_exp_f32, 4 v_min / v_max and the conversion of a pair).  With a second chain in between there is nothing to pad.
+template <int NP>
+__device__ __forceinline__ void gelu_bf16_lockstep(f32x2 (&y)[NP]) {
+    constexpr float kClamp = 5.656854249492381f;  // 4 sqrt2
+    constexpr float c[7] = {-1.000037431716919f,   -1.1505244970321655f,   -0.4605136811733246f,  -0.05179140716791153f,
+                            0.007414536084979773f, -0.0006474481779150665f, 2.524326555430889e-05f};
+    f32x2 t[NP], q[NP];
+#pragma unroll
+    for (int v = 0; v < NP; ++v) {
+        t[v] = f32x2{fminf(__builtin_fabsf(y[v].x), kClamp), fminf(__builtin_fabsf(y[v].y), kClamp)};
+        q[v] = __builtin_elementwise_fma(f32x2{c[6], c[6]}, t[v], f32x2{c[5], c[5]});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 4; k >= 0; --k) {
+#pragma unroll
+        for (int v = 0; v < NP; ++v) q[v] = __builtin_elementwise_fma(q[v], t[v], f32x2{c[k], c[k]});
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int v = 0; v < NP; ++v) q[v] = f32x2{__builtin_amdgcn_exp2f(q[v].x), __builtin_amdgcn_exp2f(q[v].y)};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < NP; ++v) y[v] = __builtin_elementwise_fma(-t[v], q[v], __builtin_elementwise_max(y[v], f32x2{0.f, 0.f}));
+}
+
 // Workgroup id -> tile id such that ids sharing an XCD (id % 8) get consecutive tiles.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, rem = nwg & 7;
