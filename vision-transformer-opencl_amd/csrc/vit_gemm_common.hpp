@@ -234,6 +234,9 @@ __device__ __forceinline__ void fold_preload(FoldOperands<TN, TM> &fold, const f
 __device__ __forceinline__ float fold_center(float acc, float mean, float colsum) { return __builtin_fmaf(-mean, colsum, acc); }
 __device__ __forceinline__ float fold_scale(float centered, float rstd, float bias) { return __builtin_fmaf(rstd, centered, bias); }
 
+#ifndef FOLD_HOIST
+#define FOLD_HOIST 1  // centred-weight fold: read the rstd of all the lane's rows before the first block's values (A/B switch)
+#endif
 template <int BM, int BN, int WM, int WN, int EPI, int AMODE>
 __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16 (&acc)[WM / 32][WN / 32],
                                                const float (&bias_r)[WN / 32], int m0, int n0, int wm, int wn,
@@ -257,30 +260,20 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
             // workgroup while the CU's other workgroup saturates the matrix pipe, each waits its turn and the FMAs wait for it -- stamps
             // put the fold's epilogue at 9.5k cycles per QKV tile against 5.1k for the plain one (round 5).
             const bool center = p.ln_colsum != nullptr;  // workgroup-uniform
-            float b_op[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b_op[j] = h == 0 ? fold.colsum[j] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int lr0 = wm * WM + i * 32;
-                f32x16 centered[TN];
-                if (center) {
-                    const float mean = fold.preloaded ? fold.mean[i] : fold.rows[lr0 + r].y;
-                    const float a_op = h == 0 ? -mean : 0.0f;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) centered[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op, b_op[j], acc[i][j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) centered[j] = acc[i][j];
-                }
-                float row_rstd[16];
+            // Two code paths, chosen once per tile (a copy "centered = acc" on the path that does not centre cost 60 registers).
+            // HOIST: the rstd of ALL the lane's rows first (LDS reads in the persistent walk) -- one exposed LDS round trip per tile
+            // instead of one per 32-row block: they queue behind the fragment reads of the CU's other workgroup, and the scheduling
+            // fences of the GELU batches keep the second block's reads from being issued before the first block's stores.
+            auto rstd_of_block = [&](int i, float (&dst)[16]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int lr = lr0 + 4 * h + 8 * g;  // tile-local row of registers 4g .. 4g + 3
+                    const int lr = wm * WM + i * 32 + 4 * h + 8 * g;  // tile-local row of registers 4g .. 4g + 3
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) row_rstd[4 * g + e] = fold.preloaded ? fold.rstd[i][4 * g + e] : fold.rows[lr + e].x;
+                    for (int e = 0; e < 4; ++e) dst[4 * g + e] = fold.preloaded ? fold.rstd[i][4 * g + e] : fold.rows[lr + e].x;
                 }
-                const int mb = m0 + lr0 + 4 * h;  // row of register 0
+            };
+            auto scale_and_store = [&](int i, const f32x16 (&src)[TN], const float (&row_rstd)[16]) __attribute__((always_inline)) {
+                const int mb = m0 + wm * WM + i * 32 + 4 * h;  // row of register 0
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * WN + j * 32 + r;
@@ -289,7 +282,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
                     for (int half = 0; half < 2; ++half) {  // two batches of 8: values first (eight erf chains in lock-step), then 8 stores
                         float y[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) y[q] = fold_scale(centered[j][half * 8 + q], row_rstd[half * 8 + q], bias_r[j]);
+                        for (int q = 0; q < 8; ++q) y[q] = fold_scale(src[j][half * 8 + q], row_rstd[half * 8 + q], bias_r[j]);
                         if constexpr (GELU) gelu_erf_x8(y);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -297,6 +290,31 @@ __device__ __forceinline__ void epilogue_store(const GemmParams &p, const f32x16
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[q]), c_rsrc, c_off, ((v & 3) + 8 * (v >> 2)) * c_row, ST_NT);
                         }
                     }
+                }
+            };
+            if (center) {
+                float b_op[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_op[j] = h == 0 ? fold.colsum[j] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float mean = fold.preloaded ? fold.mean[i] : fold.rows[wm * WM + i * 32 + r].y;
+                    const float a_op = h == 0 ? -mean : 0.0f;
+                    f32x16 centered[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) centered[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op, b_op[j], acc[i][j], 0, 0, 0);
+                    float row_rstd[16];
+                    rstd_of_block(i, row_rstd);
+                    scale_and_store(i, centered, row_rstd);
+                }
+            } else {
+                float row_rstd[TM][16];
+#pragma unroll
+                for (int i = 0; i < (FOLD_HOIST ? TM : 0); ++i) rstd_of_block(i, row_rstd[i]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (!FOLD_HOIST) rstd_of_block(i, row_rstd[i]);
+                    scale_and_store(i, acc[i], row_rstd[i]);
                 }
             }
             return;
