@@ -34,3 +34,15 @@ names = ["s_jobA", "s_job2", "wait_barrier1", "pv_jobA", "pv_job2", "wait_barrie
 for w in range(8):
     seg = np.median(d[:, w, 1:7] - d[:, w, 0:6], axis=0).astype(int)
     print(json.dumps({"wave": w, **dict(zip(names, seg.tolist())), "item_total": int(np.median(d[:, w, 6] - d[:, w, 0]))}))
+
+# item cycles (s_memtime, wave 0 and wave 4) under each timing-only mode: tells a clock effect (same cycles, shorter time) from a structural one
+for mode in (0, 1, 2, 8):
+    L.vithip_attention_set_probe_mode(mode)
+    L.vithip_attention_set_debug_buffer(dbg.ptr)
+    for _ in range(2):
+        B.hip_check(L.vithip_attention_f32(None, dq.ptr, do.ptr, n, T, heads))
+    dd = dbg.numpy().astype(np.int64).reshape(256, 8, 8)
+    L.vithip_attention_set_debug_buffer(None)
+    seg = {w: np.median(dd[:, w, 1:7] - dd[:, w, 0:6], axis=0).astype(int).tolist() for w in (0, 4)}
+    print(json.dumps({"probe_mode": mode, "item_cycles_wave0": int(np.median(dd[:, 0, 6] - dd[:, 0, 0])), "segments_wave0": seg[0], "segments_wave4": seg[4]}))
+L.vithip_attention_set_probe_mode(0)
