@@ -47,6 +47,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef PP_LNF_RS
 #define PP_LNF_RS 0
 #endif
+#ifndef PP_STAGGER
+#define PP_STAGGER 0  // timing experiment: start-up phases of the persistent workgroups of the short fp32-residual GEMM, in cycles (0 = off, the product)
+#endif
+#ifndef PP_STAGGER_ALL
+#define PP_STAGGER_ALL 0  // timing experiment: the phases for every K
+#endif
 #ifndef PP_GELU_LOCKSTEP
 #define PP_GELU_LOCKSTEP 4  // pairs of the GELU epilogue advanced together: 0 (one chain after the other), 2, 4 (fc1 -1.0 % / -0.7 %, same bits)
 #endif
@@ -146,6 +152,20 @@ __global__ __launch_bounds__(PTHREADS) void gemm_bf16_pp_kernel(const Bf16Params
     const int first = xcd_remap(blockIdx.x, nwg);
     if (first >= total) return;  // workgroup-uniform
     const int nk = p.K / PBK;
+    // Timing experiment, OFF in the product (tools/build_variant.sh -DPP_STAGGER=<cycles>): start-up phases for the short fp32-residual
+    // GEMM (out_proj of ViT-B/16: K = 768, a tile is 12 K-steps and an epilogue that moves 640 KB) -- the persistent workgroups of an XCD
+    // start in four phases PP_STAGGER cycles apart, so that their read-modify-write epilogues (every CU's at the same moment otherwise,
+    // 164 MB asked of the HBM at once) do not coincide.  Round 5, profiles/r05/experiments/bf16_gemm_start_phases.jsonl: out_proj at
+    // batch 2048 -2.3 / -4.3 / -0.6 % on three boxes with 6,000-20,000 cycles, -4 % at batch 1024, +3.8 % at batch 256 (the wait is
+    // 12 us of a 138-us launch); fc2 (K = 3072) and the bf16-output GEMMs only pay the wait (+1.6 ... +4.6 % at 12,000 / 45,000),
+    // ViT-L's out_proj (K = 1024) is inside the noise.  Not a rule one can ship: the sign depends on the batch and the size on the box.
+    if constexpr (PP_STAGGER > 0 && EPI == VITHIP_BF16_EPI_F32_RESIDUAL) {
+        const int ph = (blockIdx.x >> 3) & 3;
+        if (ph && (nk <= 12 || PP_STAGGER_ALL)) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)ph * PP_STAGGER) __builtin_amdgcn_s_sleep(64);
+        }
+    }
 
     // ---- LDS-DMA source offsets: per half-tile two instructions (q) of 8 rows x 128 B.  Lane l lands at
     // (row L = 16*wave + 8q + l/8, chunk l%8) of the slot and fetches source chunk (l%8) ^ ((L>>1)&7).
