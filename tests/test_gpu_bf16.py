@@ -191,6 +191,26 @@ def test_attention_bf16_streamed_head_switch_is_bit_identical_to_single_head_lau
         assert np.array_equal(whole[i], one), i
 
 
+@pytest.mark.parametrize("T,heads,n", [(197, 12, 70), (224, 3, 230), (50, 2, 700), (33, 1, 1300)])
+def test_attention_bf16_resident_item_walk_is_bit_identical_to_single_item_launches(T, heads, n):
+    """The resident kernel's walk (round 5): K and V of the NEXT (image, head) item arrive by LDS-DMA in a second LDS image while the
+    current one multiplies, one barrier per item -- every wave's pieces landed, everybody done with the image about to be overwritten.
+    A launch of one image has at most `heads` items, one per workgroup: it never changes images.  Launches with 3.3 / 2.7 / 2.7 / 2.5
+    items per workgroup (256 workgroups, 512 for the short sequences) must give every image the same bits as the image alone -- with
+    197 and 224 tokens (7 key tiles: the last one ragged / full), 50 and 33 (rows past the last token zero-filled by the descriptor's
+    range, two workgroups per CU); twice, for run-to-run determinism."""
+    D = heads * 64
+    rng = np.random.default_rng(13)
+    vals = rng.uniform(-1.5, 1.5, (n * T, 3 * D)).astype(np.float32)
+    vals[:, :D] *= np.float32(B.QSCALE)
+    bits = B.to_bf16_bits(vals)
+    whole = B.attention_bf16io(bits, n, T, heads, q_scaled=True).reshape(n, T, D)
+    assert np.array_equal(B.attention_bf16io(bits, n, T, heads, q_scaled=True).reshape(n, T, D), whole)
+    for i in list(range(0, n, max(1, n // 12))) + [n - 1]:
+        one = B.attention_bf16io(bits[i * T:(i + 1) * T], 1, T, heads, q_scaled=True).reshape(T, D)
+        assert np.array_equal(whole[i], one), i
+
+
 BF16_PROB_TOL = 2e-2   # bf16 activations carry 8 significant bits; the fp32 bar (1e-4) does not apply here
 
 

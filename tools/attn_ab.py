@@ -26,7 +26,7 @@ for p in paths:
     fns.append(f)
 flop = 2.0 * n * 2 * heads * T * T * 64
 res = {p: [] for p in paths}
-for rnd in range(4):
+for rnd in range(int(os.environ.get("VIT_TOOL_ROUNDS", "4"))):
     for p, f, o in zip(paths, fns, outs):
         res[p].append(timed(lambda: B.hip_check(f(None, dq.ptr, o.ptr, n, T, heads, T)), reps=5, warm=2 if rnd == 0 else 1))
 ref = B.from_bf16_bits(outs[0].numpy()).astype(np.float64)

@@ -442,6 +442,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4s;
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4v lds_short4v;
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 // A fragment of O^T = V^T . P^T for d-tile dt and the 16 keys starting at key16 (a multiple of 16), in the key order
 // of the P fragment: element j of lane half h is key key16 + 8(j>>2) + 4h + (j&3).  Vs: [keys][64] bf16, swizzled as
@@ -459,18 +460,21 @@ __device__ __forceinline__ bf16x8 v_fragment_tr(const bf16_t *Vs, int key16, int
     return __builtin_bit_cast(bf16x8, both);
 }
 
-// Persistent: a workgroup walks (image, head) items; the K/V rows and the Q fragments of the NEXT item are fetched
-// into registers before the products of the current one, so the HBM round trip that used to open every workgroup
-// (one workgroup per CU fits: 164 VGPRs) hides under the matrix and softmax work.
+// Persistent: a workgroup walks (image, head) items.  K and V of the NEXT item arrive by LDS-DMA in a second LDS image and its Q
+// fragments in registers while the current item multiplies, so the HBM round trip that used to open every workgroup hides under
+// the matrix and softmax work, and ONE barrier separates two items (round 5; rounds 2-4 staged K / V through 28 registers per
+// lane and wrote them to a single LDS image between two barriers: 0.572 -> 0.561 ms per launch at batch 2048, 238 -> 213 VGPRs,
+// same bits, profiles/r05/experiments/attention_resident_bf16_dma.jsonl).
 template <int NKT>
 __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_t *__restrict__ qkv,
                                                                      bf16_t *__restrict__ out, int tokens, int heads,
                                                                      int items, int q_rows, float kScale) {
     // kScale: (1/sqrtf(64)) * log2(e) for plain q, 1 when the Q columns already hold that multiple of q (vithip_attention_bf16io_qscaled)
     constexpr int KEYS = NKT * 32;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * KEYS * HD];
-    bf16_t *const Ks = lds;                 // [KEYS][64], chunk-swizzled for row reads
-    bf16_t *const Vs = lds + KEYS * HD;     // [KEYS][64], chunk-swizzled for transposing reads
+    constexpr int IMAGE = 2 * KEYS * HD;    // one head's K and V
+    __shared__ __attribute__((aligned(1024))) bf16_t lds[2 * IMAGE];  // the current item's image and the next one's
+    const bf16_t *Ks = lds;                 // [KEYS][64], chunk-swizzled for row reads
+    const bf16_t *Vs = lds + KEYS * HD;     // [KEYS][64], chunk-swizzled for transposing reads
 
     const int D = heads * HD, ld = 3 * D;
     const int tid = threadIdx.x;
@@ -480,22 +484,33 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
     const int q0 = wave * 32;
     const bool computes = wave < nqt;  // wave-uniform
 
-    const int c8 = tid & 7;                          // 16-B chunk (8 bf16) of a 128-B row
-    constexpr int ROWS_PER_PASS = ATT_THREADS / 8;   // 64
-    constexpr int PASSES = (KEYS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-    uint4 kreg[PASSES], vreg[PASSES];
     bf16x8 qf[4];
     auto item_base = [&](int item) { return qkv + (size_t)(item / heads) * tokens * ld + (item % heads) * HD; };
-    auto fetch = [&](int item) {  // K/V rows of the whole head (all threads) + this wave's Q fragments
+    // The head's K and V go straight to LDS (buffer_load ... lds: no staging registers, no ds_write, no write phase between two
+    // barriers), 8 rows x 128 B per wave instruction, pieces dealt round-robin to the 8 waves.  The LDS side of an LDS-DMA is
+    // linear (lane l lands at byte 16 l of the piece), so both swizzles are applied to the SOURCE chunk; rows past the last token
+    // are outside the descriptor's range and read as zero.
+    auto dma = [&](int item, int img_idx) __attribute__((always_inline)) {
         const bf16_t *base = item_base(item);
+        const unsigned bytes = (unsigned)(tokens - 1) * ld * 2 + HD * 2;  // up to the end of the last token's 64 values
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(base + D), 0, bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(base + 2 * D), 0, bytes, 0x00020000);
+        bf16_t *kd = lds + img_idx * IMAGE, *vd = kd + KEYS * HD;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const int row = (tid >> 3) + it * ROWS_PER_PASS;
-            const int srow = row < tokens ? row : tokens - 1;
-            const bf16_t *src = base + (size_t)srow * ld + c8 * 8;
-            kreg[it] = *reinterpret_cast<const uint4 *>(src + D);
-            vreg[it] = *reinterpret_cast<const uint4 *>(src + 2 * D);
+        for (int k = 0; k < (KEYS / 8 + ATT_WAVES - 1) / ATT_WAVES; ++k) {
+            const int piece = wv + ATT_WAVES * k;  // 8 rows
+            if (piece < KEYS / 8) {
+                const int row = 8 * piece + (lane >> 3), cp = lane & 7;
+                const int kvoff = row * ld * 2 + ((cp ^ ((row >> 1) & 7)) * 16);
+                const int vvoff = row * ld * 2 + ((cp ^ (4 * ((row >> 1) & 1))) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t *)(kd + piece * 8 * HD), 16, kvoff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void_t *)(vd + piece * 8 * HD), 16, vvoff, 0, 0, 0);
+            }
         }
+    };
+    auto fetch_q = [&](int item) {  // this wave's Q fragments
+        const bf16_t *base = item_base(item);
         int qrow = q0 + r;
         qrow = qrow < tokens ? qrow : tokens - 1;
         const bf16_t *qsrc = base + (size_t)qrow * ld + h * 8;
@@ -505,26 +520,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
 
     int item = blockIdx.x;
     if (item >= items) return;  // workgroup-uniform
-    fetch(item);
+    int cur = 0;  // LDS image of the current item
+    dma(item, 0);
+    fetch_q(item);
     for (;;) {
-        // ---- registers -> LDS: K (swizzled rows) and V (rows, transposing-read swizzle); rows past `tokens` are zero
-#pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const int row = (tid >> 3) + it * ROWS_PER_PASS;
-            if (row < KEYS) {
-                const bool ok = row < tokens;
-                const uint4 zero = {0u, 0u, 0u, 0u};
-                const uint4 kv = ok ? kreg[it] : zero, vv = ok ? vreg[it] : zero;
-                *reinterpret_cast<uint4 *>(Ks + row * HD + ((c8 ^ ((row >> 1) & 7)) * 8)) = kv;
-                *reinterpret_cast<uint4 *>(Vs + row * HD + ((c8 ^ (4 * ((row >> 1) & 1))) * 8)) = vv;
-            }
-        }
         bf16x8 qc[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qc[ks] = qf[ks];
+        // every wave's pieces of THIS item have landed (they were issued a whole item ago, the Q fragments with them), and behind the
+        // barrier everybody has finished reading the other image (the previous item), which the next item's pieces now overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Ks = lds + cur * IMAGE;
+        Vs = Ks + KEYS * HD;
         __syncthreads();
         const int next = item + gridDim.x;
-        if (next < items) fetch(next);  // in flight during everything below
+        if (next < items) {  // in flight during everything below
+            dma(next, cur ^ 1);
+            fetch_q(next);
+        }
 
         if (computes) {
             // The two waves of a SIMD (w and w + 4) leave the barrier together and would run their matrix phases (S, then P.V) and
@@ -532,6 +545,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
             // late: their S falls into their partners' softmax, their softmax into the partners' P.V (vit_attention_stream.hip).
             if (ATT_STAGGER > 0 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(ATT_STAGGER);
             // ---- S^T = K . Q^T ------------------------------------------------------------------------
+            // (Tried in round 5: the key tiles in pairs, so that the four dependent products of a tile alternate with another tile's --
+            // hipcc lays most of a tile's four back to back.  0.5607 against 0.5623 ms: the SIMD's other wave already fills those gaps.)
             f32x16 st[NKT];
             const int sw = (r >> 1) & 7;
 #pragma unroll
@@ -625,7 +640,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
         }
         if (next >= items) break;
         item = next;
-        __syncthreads();  // everybody is done with this item's K/V before they are overwritten
+        cur ^= 1;
     }
 }
 
