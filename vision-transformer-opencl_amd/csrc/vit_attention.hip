@@ -71,6 +71,9 @@ constexpr int ATT_THREADS = 512;
 #define ATT_STAGGER 0   // measured at ViT-B/16 batch 2048: 0 / 8 / 14 / 20 x 64 cycles = 0.582 / 0.586 / 0.582 / 0.591 ms: nothing, off
 #endif
 constexpr int ATT_WAVES = ATT_THREADS / 64;
+#ifndef ATT_PROBE
+#define ATT_PROBE 0  // timing-only builds of the resident bf16 kernel (tools/build_variant.sh -DATT_PROBE=<bits>; results WRONG): 1 = no v_exp_f32,
+#endif               // 2 = no score MFMAs, 4 = no P.V MFMAs, 8 = waves 4-7 idle (no SIMD partner), 16 = no LDS-DMA after the first item
 
 #ifdef VIT_PROBES
 unsigned long long *g_attn_dbg = nullptr;  // see vithip_attention_set_debug_buffer() (probe build only)
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
     const int r = lane & 31, h = lane >> 5;
     const int nqt = (q_rows + 31) >> 5;  // only the first q_rows query rows are computed and stored
     const int q0 = wave * 32;
-    const bool computes = wave < nqt;  // wave-uniform
+    const bool computes = wave < ((ATT_PROBE & 8) ? 4 : nqt);  // wave-uniform
 
     bf16x8 qf[4];
     auto item_base = [&](int item) { return qkv + (size_t)(item / heads) * tokens * ld + (item % heads) * HD; };
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
         __syncthreads();
         const int next = item + gridDim.x;
         if (next < items) {  // in flight during everything below
-            dma(next, cur ^ 1);
+            if (!(ATT_PROBE & 16)) dma(next, cur ^ 1);
             fetch_q(next);
         }
 
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + h) ^ sw) & 7) * 8);
-                    st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qc[ks], st[kt], 0, 0, 0);
+                    if (!(ATT_PROBE & 2)) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qc[ks], st[kt], 0, 0, 0);
                 }
             }
 
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) st[kt][v] = __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
+                for (int v = 0; v < 16; ++v) st[kt][v] = (ATT_PROBE & 1) ? fmaf(st[kt][v], kScale, mxs) : __builtin_amdgcn_exp2f(fmaf(st[kt][v], kScale, mxs));
 
             // ---- O^T = V^T . P^T, and the row sums from the same pipe ---------------------------------------
             // One more MFMA per 16-key group with an all-ones A operand: every element of `lsum` becomes the sum of this lane's
@@ -605,6 +608,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bf16_kernel(const bf16_
                         bf16x8 pf;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][8 * s2 + j];
+                        if constexpr (ATT_PROBE & 4) {  // the conversions and the transposing reads stay, the products go
+#pragma unroll
+                            for (int dt = 0; dt < 2; ++dt) {
+                                const bf16x8 vf = v_fragment_tr(Vs, kt * 32 + 16 * s2, dt, lane);
+                                asm volatile("" ::"v"(vf), "v"(pf));
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt)
                             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_fragment_tr(Vs, kt * 32 + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
