@@ -123,6 +123,13 @@ def test_fp32_layernorm_fold_on_real_gamma_beta_and_massive_channels(g):
             print(f"layer {int(l)} tile {tile}: folded LN2 + fc1-shaped fp32 GEMM on real gamma/beta: max |d| = {err:.3g} of {mag(ref):.2f} "
                   f"(row max |x| {mag(r[rows]):.1f}, mean up to {float(np.abs(st9['rows'][rows, 1]).max()):.3f})")
             assert err <= 2e-5 * mag(ref), (int(l), tile)
+        # the form the engine folds with since round 5: the weight's rows centred (no column-sum term, the epilogue only scales)
+        Wc, _, bc = B.ln_fold_weights_f32_centered(W1, b1, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"])
+        for tile in (0, 9):
+            got = B.gemm(r, Wc, bc, epilogue=B.EPI_BIAS, tile=tile, ln=(st9["rows"], None))[rows]
+            err = float(np.abs(got - ref).max())
+            print(f"layer {int(l)} tile {tile}: the same with the centred weight: max |d| = {err:.3g}")
+            assert err <= 2e-5 * mag(ref), (int(l), tile, "centred")
         plain = B.gemm(B.layernorm(r, g[f"ln2_w_{l}"], g[f"ln2_b_{l}"]), W1, b1, epilogue=B.EPI_BIAS)[rows]   # the unfolded order, for scale
         print(f"layer {int(l)}: LayerNorm kernel + plain GEMM: max |d| = {float(np.abs(plain - ref).max()):.3g}")
 
